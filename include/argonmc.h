@@ -1,0 +1,245 @@
+/*
+ * argonmc.h — C ABI of libargonmc.so: the MI355X-native (gfx950, HIP) drift -> wall-reflection ->
+ * particle-particle collision sweep of the hard-sphere argon Monte Carlo.
+ *
+ * The reference (Lightbrite88/Argon_Monte_Carlo) is pure Python and has no FFI.  Every entry point below
+ * therefore cites the reference code it REPLACES (file:line under /root/reference; Cube = Open_Air_Cube_MC.py,
+ * Pore = Open_Air_Pore_MC.py, Temp = Temperature_Pore_MC.py); INTEGRATION.md shows the ctypes stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (AMC_OK) or a negative amc_status; nothing throws across the boundary;
+ *     amc_last_error(ctx) returns a string owned by the ctx (valid until the next call on that ctx).
+ *   - a ctx is driven by ONE host thread.  Host buffers are C-contiguous float64 / uint8 / int32 arrays owned by
+ *     the caller; the library copies in/out and never retains host pointers.
+ *   - all arithmetic is IEEE double, compiled with -ffp-contract=off; see DESIGN.md "numerics".
+ *   - there is NO CPU fallback: if no HIP device is usable, amc_create fails with AMC_ERR_NO_DEVICE.
+ */
+#ifndef ARGONMC_H
+#define ARGONMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMC_ABI_VERSION 1
+
+typedef enum amc_status {
+    AMC_OK = 0,
+    AMC_ERR_INVALID = -1,      /* bad argument / params                                            */
+    AMC_ERR_NO_DEVICE = -2,    /* no usable HIP device (the product path never falls back to CPU)   */
+    AMC_ERR_HIP = -3,          /* a HIP runtime call failed; see amc_last_error                      */
+    AMC_ERR_CAPACITY = -4,     /* a device work buffer overflowed (candidates, clusters, paths)       */
+    AMC_ERR_FP = -5,           /* the reference would have raised FloatingPointError (np.seterr(all='raise'),
+                                  Pore:11 / Temp:15): zero relative velocity in the contact solve etc. */
+    AMC_ERR_STATE = -6         /* call made in the wrong state (e.g. timestep before upload)          */
+} amc_status;
+
+/* Geometry kinds = which reference loop body one amc_timestep() reproduces. */
+typedef enum amc_geometry {
+    AMC_GEOM_CELL = 0,            /* a single cell: pairwise_particles_in_cell only (Pore:160-255)       */
+    AMC_GEOM_CUBE = 1,            /* Open_Air_Cube_MC.py loop body, Cube:175-338                         */
+    AMC_GEOM_PORE = 2,            /* Open_Air_Pore_MC.py loop body, Pore:416-557 (specular walls)        */
+    AMC_GEOM_PORE_ENERGISED = 3   /* Temperature_Pore_MC.py loop body, Temp:662-853                      */
+} amc_geometry;
+
+/*
+ * Constants of one simulation.  The HOST evaluates every threshold with exactly the expression the reference
+ * writes (e.g. Pore's gap top is (total_height - open_air_height) - cold_coating_height = 1.6000000000000059e-07,
+ * Temp's is open_air_height + hot_coating_height + gap_height = 1.6000000000000003e-07) and passes the resulting
+ * doubles; device code never re-derives them.  argon_monte_carlo_amd/params.py builds this struct.
+ */
+typedef struct amc_params {
+    int32_t struct_size;          /* = sizeof(amc_params), ABI check                                   */
+    int32_t geometry;             /* amc_geometry                                                      */
+    int64_t n;                    /* number of particles (num_molecules, Pore:64)                      */
+
+    double collision_range;       /* Pore:58                                                           */
+    double argon_mass;            /* Pore:49                                                           */
+    double argon_radius;          /* Pore:56                                                           */
+
+    /* reference cell grid of the p-p sweep (Cube:30-38,233-237; Pore:41-46,527-529) */
+    int32_t nx, ny, nz;           /* num_{x,y,z}_subdivions                                            */
+    int32_t reserved0;
+    double dx, dy, dz;
+    double overlap_x, overlap_y, overlap_z;   /* Cube: d/10 ; Pore/Temp: collision_range                */
+
+    /* Cube walls (Cube:189-226) */
+    double cube_x, cube_y, cube_z;
+
+    /* Pore / Temp radii and heights (Pore:25-39,67-69) */
+    double R_oa, R_oa_c;          /* open_air_radius, open_air_collision_radius                        */
+    double R_p, R_p_c;            /* pore_coated_radius, pore_collision_radius                         */
+    double R_g, R_g_c;            /* gap_radius, gap_collision_radius                                  */
+    double H;                     /* total_height                                                      */
+    double h_oa;                  /* open_air_height                                                   */
+    double z_cold;                /* total_height - open_air_height                                    */
+    double z_gap_bottom;          /* open_air_height + hot_coating_height                              */
+    double z_gap_top;             /* Pore: total_height-open_air_height-cold_coating_height ; Temp: gap_top_height */
+
+    /* bounds check / recapture (Pore:354-375; Temp:594-616) */
+    double oob_z_lo_fix;          /* Pore: 10*argon_radius (added)      ; Temp: 50e-9 (assigned)       */
+    double oob_z_hi_fix;          /* Pore: 10*argon_radius (subtracted) ; Temp: total_height-50e-9      */
+    double R_oa_sq, R_g_sq, R_p_sq;           /* open_air_radius**2 etc. as Python evaluates them      */
+    double z_oob_hot_top;         /* open_air_height + hot_coating_height                              */
+    double z_oob_gap_top;         /* open_air_height + hot_coating_height + gap_height                 */
+
+    /* Temp-only thresholds (Temp:690-753), all pre-evaluated */
+    double t_z3_cold;             /* total_height - open_air_height + argon_radius                     */
+    double t_z3_hot;              /* open_air_height - argon_radius                                    */
+    double t_zgap_lo;             /* gap_bottom_height + argon_radius                                  */
+    double t_zgap_hi;             /* gap_top_height - argon_radius                                     */
+    double R_g_c_sq, R_p_c_sq;    /* gap_collision_radius**2, pore_collision_radius**2                 */
+    double E_cold, E_hot;         /* surface_energy_{cold,hot} (Temp:83-84)                            */
+    double alpha_coated, alpha_gap;           /* Temp:76-77                                            */
+    double cos85;                 /* cos(85*pi/180) (Temp:136)                                         */
+
+    /* free-path histogram (Pore:93,575): nbins equal bins on [hist_lo, hist_hi] */
+    int32_t hist_bins;
+    int32_t reserved1;
+    double hist_lo, hist_hi;
+
+    /* engine knobs (not physics) */
+    double fine_cell;             /* edge of the detection grid cells (m); 0 = choose automatically     */
+    int32_t device;               /* HIP device ordinal                                                */
+    int32_t detect_mode;          /* 0 auto, 1 binned (cell grid), 2 tiled all-pairs                   */
+    int64_t max_candidates;       /* capacity of the candidate-pair list; 0 = default                  */
+    int64_t max_paths;            /* capacity of the completed-path record buffer; 0 = default         */
+} amc_params;
+
+/* Per-step counters.  n_collisions = what the reference accumulates in num_collisions_per_step (Pore:424,
+ * 244-245, 292, 348, 556): wall hits that count + p-p collisions. */
+typedef struct amc_step_stats {
+    int64_t n_pp;                 /* particle-particle collisions (Pore:241)                           */
+    int64_t n_wall;               /* wall hits counted by the reference (Pore:292,348; Temp:411,482,552) */
+    int64_t n_oob_walls;          /* particles moved by the bounds check after the wall stage (Pore:512; Temp:804) */
+    int64_t n_oob_pp;             /* ... after the p-p sweep (Pore:550; Temp:844)                      */
+    int64_t n_paths;              /* completed free paths emitted this step                            */
+    int64_t n_candidates;         /* close pairs found by the detect kernel                            */
+    int64_t n_clusters;           /* interaction clusters resolved                                     */
+    int64_t n_rounds;             /* resolve validation rounds (1 = no cluster merge was needed)       */
+    int64_t n_fp_errors;          /* events where the reference would raise (a == 0, negative discriminant) */
+    int64_t flags;                /* bit0 candidate overflow, bit1 path overflow, bit2 cluster overflow */
+} amc_step_stats;
+
+/* One completed free path (Pore:186-199, 274-278, 324-328).  (step, phase, cell, i, j, which) is the position of
+ * the append in the reference's own order, so sorting records by those keys reproduces its list order:
+ *   phase 1..9  = wall cases in evaluation order (Pore:442-485 / Temp:693-753), i = particle, j = -1
+ *   phase 16+g  = p-p colour group g = 4*x_group+2*y_group+z_group (Pore:522-524); Cube uses phase 16
+ *   cell        = linear reference-cell index ((lx*ny)+ly)*nz+lz ; which = 0 for particle j, 1 for particle i */
+typedef struct amc_path_record {
+    int32_t step;
+    int32_t phase;
+    int64_t cell;
+    int32_t i;
+    int32_t j;
+    int32_t which;
+    int32_t reserved;
+    double total, px, py, pz;
+} amc_path_record;
+
+typedef struct amc_ctx amc_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+int amc_abi_version(void);
+int amc_create(amc_ctx **out, const amc_params *p);
+void amc_destroy(amc_ctx *ctx);
+const char *amc_last_error(const amc_ctx *ctx);
+/* Run all subsequent work on this hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
+int amc_set_stream(amc_ctx *ctx, void *hip_stream);
+int amc_synchronize(amc_ctx *ctx);
+
+/* ---- state (replaces the module-global ndarrays of Pore:385-400) ----------------------------------------- */
+/* x_vals,y_vals,z_vals,x_velocities,y_velocities,z_velocities, dist_since_collision, dist_{x,y,z}_since_collision,
+ * full_path_traveled — float64[n] each, uint8[n] for the flag.  Any pointer may be NULL = leave unchanged / skip. */
+int amc_upload(amc_ctx *ctx, const double *x, const double *y, const double *z, const double *vx, const double *vy,
+               const double *vz, const double *dist, const double *dist_x, const double *dist_y,
+               const double *dist_z, const uint8_t *full_path);
+int amc_download(amc_ctx *ctx, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *dist,
+                 double *dist_x, double *dist_y, double *dist_z, uint8_t *full_path);
+/* prior_{x,y,z}_vals (Pore:427-429) of the last step */
+int amc_download_prior(amc_ctx *ctx, double *px, double *py, double *pz);
+
+/* ---- the hot path -------------------------------------------------------------------------------------- */
+/* One iteration of the reference's time loop body: drift (Pore:426-437) -> wall cases (Pore:439-485 | Cube:189-226)
+ * -> bounds check (Pore:512) -> p-p sweep (Pore:520-549 | Cube:231-336) -> bounds check (Pore:550).
+ * Blocks until the step is done and returns its counters. */
+int amc_timestep(amc_ctx *ctx, double dt, amc_step_stats *out);
+/* nsteps iterations enqueued back-to-back with no host synchronisation in between; *sum receives the counters
+ * summed over the steps (may be NULL).  Not available for AMC_GEOM_PORE_ENERGISED (host RNG handshake per step). */
+int amc_run(amc_ctx *ctx, double dt, int64_t nsteps, amc_step_stats *sum);
+
+/* individual stages, for function-level parity tests against the reference's handlers */
+int amc_stage_drift(amc_ctx *ctx, double dt);                 /* Pore:426-437 / Cube:179-187            */
+int amc_stage_walls(amc_ctx *ctx, amc_step_stats *out);      /* Pore:439-485 / Cube:189-226             */
+int amc_stage_bounds(amc_ctx *ctx, int64_t *n_moved);        /* Pore:354-375 / Temp:594-616             */
+int amc_stage_sweep(amc_ctx *ctx, amc_step_stats *out);      /* Pore:520-549 / Cube:231-336             */
+
+/* Direct replacement of pairwise_particles_in_cell (Pore:160-255 == Temp:215-309 == Cube:253-324) for ONE cell:
+ * arrays of length n_cell are updated in place exactly as the reference returns them; completed paths are
+ * appended in the reference's order to out_paths[4][cap] (total,x,y,z rows); returns the collision count that the
+ * reference adds to num_collisions_per_step.  Needs a ctx only for its device/stream and scratch. */
+int amc_pairwise_cell(amc_ctx *ctx, int64_t n_cell, double *continue_path, double *continue_x_path,
+                      double *continue_y_path, double *continue_z_path, uint8_t *has_collided, double *x, double *y,
+                      double *z, double *vx, double *vy, double *vz, double *out_paths, size_t cap,
+                      size_t *n_paths, int64_t *n_collisions);
+
+/* ---- energised walls: host-RNG handshake (Temp:132-141 consumes two Mersenne-Twister streams in particle order,
+ * Temp:147-152 calls mpmath.quad per gap hit — both stay on the host) ------------------------------------------ */
+/* amc_wall_hits: evaluates the mask of energised case `case_id` (3..9 in evaluation order, Temp:708-751) on the
+ * current state, returns hit particle indices in ascending order, their inward unit normals and contact z. */
+int amc_wall_hits(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, size_t cap,
+                  size_t *n);
+/* amc_wall_apply: applies re-emission for those hits: unit direction (3 per hit) and surface energy per hit;
+ * returns the summed z-momentum and energy change exactly as Temp:384-389 accumulates them (in hit order). */
+int amc_wall_apply(amc_ctx *ctx, int case_id, const double *dir_xyz, const double *surface_energy, size_t n,
+                   double *dpz_sum, double *dE_sum);
+
+/* ---- outputs -------------------------------------------------------------------------------------------- */
+/* completed_paths / completed_{x,y,z}_paths (Pore:408-413) since the last drain, unsorted */
+int amc_drain_paths(amc_ctx *ctx, amc_path_record *out, size_t cap, size_t *n);
+int amc_paths_pending(amc_ctx *ctx, size_t *n);
+/* free-path histograms accumulated on the device with np.histogram(range=(lo,hi), bins) semantics
+ * (Pore:575-596): counts[4][hist_bins] (total, x, y, z) and the number of paths seen (incl. out of range). */
+int amc_histograms(amc_ctx *ctx, uint64_t *counts, uint64_t *n_paths_total);
+int amc_reset_outputs(amc_ctx *ctx);
+
+/* ---- multi-GPU (one process per GPU; particles sharded by index range, Survey 8e) ------------------------ */
+/* This rank owns particles [lo, hi).  Default [0, n). */
+int amc_set_shard(amc_ctx *ctx, int64_t lo, int64_t hi);
+/* Raw device pointers for the collectives the host runs with torch.distributed (RCCL): positions are float64[n]
+ * each (all-gathered per step); xchg is the candidate-exchange buffer (amc_mg_* below). */
+typedef struct amc_device_view {
+    void *x, *y, *z;              /* float64[n]                                                         */
+    void *xchg_send;              /* this rank's packed candidate records                              */
+    void *xchg_recv;              /* world_size * xchg_stride bytes                                    */
+    int64_t xchg_stride;          /* bytes per rank slot                                               */
+    int64_t xchg_record_bytes;
+} amc_device_view;
+int amc_device_view_get(amc_ctx *ctx, int world_size, amc_device_view *out);
+int amc_mg_local(amc_ctx *ctx, double dt);                    /* drift + walls + bounds on [lo,hi)      */
+int amc_mg_detect_pack(amc_ctx *ctx, int64_t *n_records);     /* after the position all-gather          */
+int amc_mg_resolve(amc_ctx *ctx, int world_size, const int64_t *n_records_per_rank, amc_step_stats *out);
+int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);         /* bounds check after the sweep on [lo,hi) */
+
+/* ---- measurement ----------------------------------------------------------------------------------------- */
+/* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
+#define AMC_K_DRIFT_WALLS 0
+#define AMC_K_BIN_COUNT 1
+#define AMC_K_BIN_SCAN 2
+#define AMC_K_BIN_SCATTER 3
+#define AMC_K_DETECT 4
+#define AMC_K_RESOLVE 5
+#define AMC_K_BOUNDS 6
+#define AMC_K_COUNT 8
+int amc_profile(amc_ctx *ctx, int enable);
+int amc_kernel_times(amc_ctx *ctx, double *total_ms /*[AMC_K_COUNT]*/, int64_t *launches /*[AMC_K_COUNT]*/);
+const char *amc_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARGONMC_H */

@@ -1,0 +1,412 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF (build container only).
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py [--only func|cube|pore|consts]
+
+* function level: imports /root/reference/Open_Air_Pore_MC.py (its main loop is __main__-guarded) and calls
+  pairwise_particles_in_cell / hit_vertical_wall / hit_cylinder_side_wall / num_out_of_bounds on seeded inputs.
+* step level: writes a PATCHED TEMPORARY COPY of a reference script into a scratch directory under /tmp
+  (single-line substitutions of num_molecules / sigma / slice count / loop bound, plus calls to a dump hook after
+  every step), runs it there as a script and collects the dumps.  Nothing of the reference's text is stored in
+  the repository: the fixtures hold only inputs, outputs and the patch PARAMETERS.
+
+The reference does not exist on the GPU box; the fixtures travel instead.
+"""
+import argparse
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+STATE_KEYS = ["x_vals", "y_vals", "z_vals", "x_velocities", "y_velocities", "z_velocities", "dist_since_collision",
+              "dist_x_since_collision", "dist_y_since_collision", "dist_z_since_collision", "full_path_traveled"]
+
+
+# ------------------------------------------------------------------------------------------------ function level
+def gen_func():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, REF)
+    import multiprocessing
+    import Open_Air_Pore_MC as P  # noqa
+
+    rng = np.random.default_rng(20240917)
+    cr = float(P.collision_range)
+    out = {}
+
+    # --- (i) single pairs -------------------------------------------------------------------------------
+    npair = 1000
+    fields = ["cont", "cx", "cy", "cz", "flag", "x", "y", "z", "vx", "vy", "vz"]
+    pin = {k: np.zeros((npair, 2)) for k in fields}
+    pout = {k: np.zeros((npair, 2)) for k in fields}
+    paths = np.full((npair, 2, 4), np.nan)
+    npaths = np.zeros(npair, dtype=np.int64)
+    ncoll = np.zeros(npair, dtype=np.int64)
+    for k in range(npair):
+        ctr = Value = None
+        counter = multiprocessing.Value('i', 0)
+        P.init_globals(counter)
+        base = rng.uniform(-1e-7, 1e-7, 3) + np.array([0, 0, 1.5e-6])
+        sep = cr * rng.uniform(0.05, 1.3 if k % 5 == 0 else 0.999)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        pos = np.stack([base, base + sep * u])
+        vel = rng.normal(size=(2, 3)) * 249.0
+        if k % 3 == 0:  # make them approach head-on-ish
+            vel[1] = vel[0] - u * abs(rng.normal()) * 300 + rng.normal(size=3) * 30
+        cont = rng.uniform(0, 2e-7, (2, 4))
+        cont[:, 0] = np.sqrt((cont[:, 1:] ** 2).sum(1)) * rng.uniform(1, 1.5)
+        flag = rng.integers(0, 2, 2).astype(bool)
+        args = [cont[:, 0].copy(), cont[:, 1].copy(), cont[:, 2].copy(), cont[:, 3].copy(), flag.copy(),
+                pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy()]
+        for f, a in zip(fields, args):
+            pin[f][k] = a
+        lists = [[], [], [], []]
+        res = P.pairwise_particles_in_cell(lists[0], lists[1], lists[2], lists[3], np.array([True, True]), *args)
+        for f, a in zip(fields, res[1:]):
+            pout[f][k] = a
+        npaths[k] = len(lists[0])
+        for q in range(len(lists[0])):
+            paths[k, q] = [lists[0][q], lists[1][q], lists[2][q], lists[3][q]]
+        ncoll[k] = counter.value
+    for f in fields:
+        out["pair_in_" + f] = pin[f]
+        out["pair_out_" + f] = pout[f]
+    out["pair_paths"] = paths
+    out["pair_npaths"] = npaths
+    out["pair_ncoll"] = ncoll
+
+    # --- (ii) whole cells with chained collisions -----------------------------------------------------------
+    ncells = 24
+    cell_sizes = rng.integers(40, 301, ncells)
+    cell_sizes[:4] = [2, 3, 5, 300]
+    off = np.concatenate([[0], np.cumsum(cell_sizes)])
+    tot = int(off[-1])
+    cin = {k: np.zeros(tot) for k in fields}
+    cout = {k: np.zeros(tot) for k in fields}
+    cpaths = []
+    cpath_off = [0]
+    cncoll = np.zeros(ncells, dtype=np.int64)
+    for c in range(ncells):
+        n = int(cell_sizes[c])
+        counter = multiprocessing.Value('i', 0)
+        P.init_globals(counter)
+        # pack n spheres into a box whose volume gives ~8-25% volume fraction => several overlaps + chains
+        vf = rng.uniform(0.08, 0.25)
+        side = (n * (4.0 / 3.0) * np.pi * (cr / 2) ** 3 / vf) ** (1.0 / 3.0)
+        pos = rng.uniform(0, side, (n, 3)) + np.array([1e-8, -2e-8, 1.2e-6])
+        vel = rng.normal(size=(n, 3)) * 249.0
+        cont = rng.uniform(0, 2e-7, (n, 4))
+        flag = rng.integers(0, 2, n).astype(bool)
+        args = [cont[:, 0].copy(), cont[:, 1].copy(), cont[:, 2].copy(), cont[:, 3].copy(), flag.copy(),
+                pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), vel[:, 0].copy(), vel[:, 1].copy(), vel[:, 2].copy()]
+        for f, a in zip(fields, args):
+            cin[f][off[c]:off[c + 1]] = a
+        lists = [[], [], [], []]
+        res = P.pairwise_particles_in_cell(lists[0], lists[1], lists[2], lists[3], np.ones(n, dtype=bool), *args)
+        for f, a in zip(fields, res[1:]):
+            cout[f][off[c]:off[c + 1]] = a
+        cpaths.extend(zip(*lists))
+        cpath_off.append(len(cpaths))
+        cncoll[c] = counter.value
+    for f in fields:
+        out["cell_in_" + f] = cin[f]
+        out["cell_out_" + f] = cout[f]
+    out["cell_off"] = off
+    out["cell_paths"] = np.array(cpaths, dtype=np.float64).reshape(-1, 4)
+    out["cell_path_off"] = np.array(cpath_off)
+    out["cell_ncoll"] = cncoll
+
+    # --- (iii) wall handlers --------------------------------------------------------------------------------
+    def set_state(n):
+        st = {}
+        st["x_vals"] = rng.uniform(-1.6e-7, 1.6e-7, n)
+        st["y_vals"] = rng.uniform(-1.6e-7, 1.6e-7, n)
+        st["z_vals"] = rng.uniform(-2e-8, 3.22e-6, n)
+        for k in ["x_velocities", "y_velocities", "z_velocities"]:
+            st[k] = rng.normal(size=n) * 249.0
+        for k in ["dist_since_collision", "dist_x_since_collision", "dist_y_since_collision", "dist_z_since_collision"]:
+            st[k] = rng.uniform(0, 3e-7, n)
+        st["full_path_traveled"] = rng.integers(0, 2, n).astype(bool)
+        return st
+
+    def load(st):
+        for k, v in st.items():
+            setattr(P, k, v.copy())
+
+    def grab():
+        return {k: getattr(P, k).copy() for k in STATE_KEYS}
+
+    nw = 600
+    # vertical walls at several planes
+    vplanes = [0.0, float(P.total_height), float(P.total_height - P.open_air_height), float(P.open_air_height),
+               float(P.open_air_height + P.hot_coating_height)]
+    for q, zp in enumerate(vplanes):
+        st = set_state(nw)
+        hits = rng.random(nw) < 0.4
+        load(st)
+        counter = multiprocessing.Value('i', 0)
+        P.num_collisions_per_step = counter
+        lists = [[], [], [], []]
+        P.hit_vertical_wall(hits, zp, *lists)
+        res = grab()
+        for k in STATE_KEYS:
+            out[f"vwall{q}_in_{k}"] = st[k]
+            out[f"vwall{q}_out_{k}"] = res[k]
+        out[f"vwall{q}_hits"] = hits
+        out[f"vwall{q}_plane"] = np.float64(zp)
+        out[f"vwall{q}_paths"] = np.array(list(zip(*lists)), dtype=np.float64).reshape(-1, 4)
+        out[f"vwall{q}_ncoll"] = np.int64(counter.value)
+    # side walls: particles just outside radius R moving outward (as after a drift step)
+    radii = [(float(P.open_air_radius), float(P.open_air_collision_radius)),
+             (float(P.gap_radius), float(P.gap_collision_radius)),
+             (float(P.pore_coated_radius), float(P.pore_collision_radius))]
+    for q, (R, Rc) in enumerate(radii):
+        st = set_state(nw)
+        # start strictly inside Rc, fly along v until r = R*(1+eps): the back-solve then always has real roots
+        th = rng.uniform(0, 2 * np.pi, nw)
+        r0 = Rc * rng.uniform(0.3, 0.999, nw)
+        x0, y0 = r0 * np.cos(th), r0 * np.sin(th)
+        vx, vy = rng.normal(size=nw) * 249.0, rng.normal(size=nw) * 249.0
+        rt = R * (1 + rng.uniform(1e-6, 3e-3, nw))
+        qa, qb, qc = vx * vx + vy * vy, 2 * (x0 * vx + y0 * vy), x0 * x0 + y0 * y0 - rt * rt
+        s = (-qb + np.sqrt(qb * qb - 4 * qa * qc)) / (2 * qa)
+        st["x_vals"] = x0 + vx * s
+        st["y_vals"] = y0 + vy * s
+        st["x_velocities"] = vx
+        st["y_velocities"] = vy
+        hits = rng.random(nw) < 0.5
+        load(st)
+        counter = multiprocessing.Value('i', 0)
+        P.num_collisions_per_step = counter
+        lists = [[], [], [], []]
+        P.hit_cylinder_side_wall(hits, Rc, *lists)
+        res = grab()
+        for k in STATE_KEYS:
+            out[f"swall{q}_in_{k}"] = st[k]
+            out[f"swall{q}_out_{k}"] = res[k]
+        out[f"swall{q}_hits"] = hits
+        out[f"swall{q}_Rc"] = np.float64(Rc)
+        out[f"swall{q}_paths"] = np.array(list(zip(*lists)), dtype=np.float64).reshape(-1, 4)
+        out[f"swall{q}_ncoll"] = np.int64(counter.value)
+
+    # --- (iv) the mutating bounds check -------------------------------------------------------------------
+    st = set_state(4000)
+    st["x_vals"] *= 1.2
+    load(st)
+    cnt = P.num_out_of_bounds()
+    res = grab()
+    for k in ["x_vals", "y_vals", "z_vals"]:
+        out[f"oob_in_{k}"] = st[k]
+        out[f"oob_out_{k}"] = res[k]
+    out["oob_count"] = np.int64(cnt)
+
+    # --- SURVEY 8c known-answer vector ------------------------------------------------------------------------
+    counter = multiprocessing.Value('i', 0)
+    P.init_globals(counter)
+    lists = [[], [], [], []]
+    res = P.pairwise_particles_in_cell(*lists, np.array([True, True]), np.array([1e-8, 2e-8]), np.array([1e-8, 2e-8]),
+                                       np.zeros(2), np.zeros(2), np.array([True, False]), np.array([0.0, 0.9 * cr]),
+                                       np.zeros(2), np.zeros(2), np.array([100.0, -100.0]), np.zeros(2), np.zeros(2))
+    out["kat_x"] = res[6]
+    out["kat_vx"] = res[9]
+    out["kat_cont"] = res[1]
+    out["kat_paths"] = np.array([lists[0][0], lists[1][0], lists[2][0], lists[3][0]])
+
+    np.savez_compressed(os.path.join(OUT, "func_pore.npz"), **out)
+    print("func_pore.npz:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------------ constants
+def gen_consts():
+    """Module constants of the three scripts, captured from the reference's own evaluation."""
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, REF)
+    import Open_Air_Pore_MC as P  # noqa
+    import Temperature_Pore_MC as T  # noqa
+    names = ["pore_coated_radius", "gap_radius", "pore_height", "hot_coating_height", "gap_height",
+             "cold_coating_height", "open_air_radius", "open_air_height", "total_volume", "total_height", "dx", "dy",
+             "dz", "argon_mass", "argon_radius", "collision_range", "lambda_mfp", "v_mean", "a_shape", "num_molecules",
+             "open_air_collision_radius", "gap_collision_radius", "pore_collision_radius", "tau", "dt",
+             "open_air_particles", "cold_pore_particles", "hot_pore_particles", "gap_particles", "remaining_particles"]
+    out = {}
+    for mod, tag in ((P, "pore"), (T, "temp")):
+        for k in names:
+            out[f"{tag}_{k}"] = np.float64(getattr(mod, k))
+    out["pore_z_gap_top_expr"] = np.float64(P.total_height - P.open_air_height - P.cold_coating_height)
+    out["pore_z_gap_bottom_expr"] = np.float64(P.open_air_height + P.hot_coating_height)
+    out["temp_gap_bottom_height"] = np.float64(T.gap_bottom_height)
+    out["temp_gap_top_height"] = np.float64(T.gap_top_height)
+    out["temp_surface_energy_cold"] = np.float64(float(T.surface_energy_cold))
+    out["temp_surface_energy_hot"] = np.float64(float(T.surface_energy_hot))
+    out["temp_R_g_c_sq"] = np.float64(T.gap_collision_radius ** 2)
+    out["temp_R_p_c_sq"] = np.float64(T.pore_collision_radius ** 2)
+    out["pore_R_oa_sq"] = np.float64(P.open_air_radius ** 2)
+    out["pore_R_g_sq"] = np.float64(P.gap_radius ** 2)
+    out["pore_R_p_sq"] = np.float64(P.pore_coated_radius ** 2)
+    # Cube cannot be imported without running its simulation: evaluate only its constant block (the lines before
+    # the RNG seeding) in a scratch namespace
+    src = open(os.path.join(REF, "Open_Air_Cube_MC.py")).read().split("\n")
+    end = next(i for i, l in enumerate(src) if l.startswith("np.random.seed"))
+    ns = {}
+    block = "\n".join(l for l in src[:end] if not l.startswith("print("))
+    exec(compile(block, "<cube-constants>", "exec"), ns)
+    for k in ["cube_x", "dx", "collision_x_overlap", "argon_radius", "collision_range", "lambda_mfp", "v_mean",
+              "a_shape", "num_molecules", "tau", "dt", "num_timesteps"]:
+        out[f"cube_{k}"] = np.float64(ns[k])
+    np.savez_compressed(os.path.join(OUT, "consts.npz"), **out)
+    print("consts.npz:", len(out), "values")
+
+
+# ------------------------------------------------------------------------------------------------ step level
+HOOK = r'''
+import sys, numpy as np
+_KEYS = %r
+_snap_steps = set(%r)
+_store = {}
+def dump(step, ncoll=None, lists=None):
+    m = sys.modules['__main__']
+    g = m.__dict__
+    def arr(k):
+        a = np.asarray(g[k])
+        return a.reshape(-1).copy()
+    if step in _snap_steps:
+        for k in _KEYS:
+            _store['s%%04d_%%s' %% (step, k)] = arr(k)
+    st = _store.setdefault('per_step', [])
+    if step >= 0:
+        vx, vy, vz = arr('x_velocities'), arr('y_velocities'), arr('z_velocities')
+        st.append([step, -1 if ncoll is None else int(ncoll), -1 if lists is None else len(lists[0]),
+                   float(np.sum(arr('x_vals'))), float(np.sum(arr('y_vals'))), float(np.sum(arr('z_vals'))),
+                   float(np.sum(vx)), float(np.sum(vy)), float(np.sum(vz)), float(np.sum(vx*vx+vy*vy+vz*vz)),
+                   float(np.sum(arr('dist_since_collision'))), float(np.sum(arr('full_path_traveled')))])
+def finish(lists, extra=None):
+    _store['per_step'] = np.array(_store.get('per_step', []), dtype=np.float64).reshape(-1, 12)
+    for name, l in zip(['completed_paths', 'completed_x_paths', 'completed_y_paths', 'completed_z_paths'], lists):
+        _store[name] = np.array(list(l), dtype=np.float64)
+    if extra:
+        for k, v in extra.items():
+            _store[k] = np.asarray(v)
+    np.savez_compressed('golden_dump.npz', **_store)
+'''
+
+
+def _patch_lines(lines, subs):
+    """subs: list of (regex matching a whole source line, replacement-or-callable).  Each must hit exactly once."""
+    for pat, rep in subs:
+        idx = [i for i, l in enumerate(lines) if re.match(pat, l)]
+        if len(idx) != 1:
+            raise RuntimeError(f"pattern {pat!r} matched {len(idx)} lines")
+        i = idx[0]
+        lines[i] = rep(lines[i]) if callable(rep) else rep
+    return lines
+
+
+def _indent_of(line):
+    return line[:len(line) - len(line.lstrip())]
+
+
+def run_patched(script, subs, inserts, snap_steps, out_name, meta, timeout=3600):
+    """inserts: list of (regex of anchor line, 'before'|'after', code string using the anchor's indentation)."""
+    work = tempfile.mkdtemp(prefix="amc_golden_", dir="/tmp")
+    try:
+        lines = open(os.path.join(REF, script)).read().split("\n")
+        lines = _patch_lines(lines, subs)
+        for pat, where, code in inserts:
+            idx = [i for i, l in enumerate(lines) if re.match(pat, l)]
+            if len(idx) != 1:
+                raise RuntimeError(f"anchor {pat!r} matched {len(idx)} lines")
+            i = idx[0]
+            ind = _indent_of(lines[i])
+            new = [ind + c for c in code.split("\n")]
+            lines[i + 1:i + 1] = new if where == "after" else []
+            if where == "before":
+                lines[i:i] = new
+        lines.insert(0, "import _golden_hook")
+        with open(os.path.join(work, "patched.py"), "w") as f:
+            f.write("\n".join(lines))
+        with open(os.path.join(work, "_golden_hook.py"), "w") as f:
+            f.write(HOOK % (STATE_KEYS, sorted(snap_steps)))
+        shutil.copy(os.path.join(REF, "utils.py"), os.path.join(work, "utils.py"))
+        env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1")
+        r = subprocess.run([sys.executable, "-u", "patched.py"], cwd=work, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=timeout)
+        tail = r.stdout.decode(errors="replace")[-3000:]
+        if r.returncode != 0:
+            print(tail)
+            raise RuntimeError(f"{script} patched run failed rc={r.returncode}")
+        d = dict(np.load(os.path.join(work, "golden_dump.npz")))
+        for k, v in meta.items():
+            d["meta_" + k] = np.asarray(v)
+        # the text outputs the script wrote (format goldens)
+        for fn in sorted(os.listdir(work)):
+            if fn.startswith("hist_") and fn.endswith(".txt") or fn == "momentum_energy.csv":
+                d["file_" + fn] = np.frombuffer(open(os.path.join(work, fn), "rb").read(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, out_name), **d)
+        print(out_name, "written;", "steps:", d["per_step"].shape[0], "paths:", d["completed_paths"].shape[0])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def gen_pore(tag, K, sigma_mult, slice_, steps, snaps):
+    subs = [
+        (r"^num_molecules\s+= np\.round\(", f"num_molecules       = np.int64({K})"),
+        (r"^sigma\s+= 3\.6", f"sigma               = 3.6 * 10**(-19) * {sigma_mult}"),
+        (r"^NMFT_slice\s+= 1000", f"NMFT_slice          = {slice_}"),
+        (r"^        for i in range\(num_timesteps\):", f"        for i in range({steps}):"),
+    ]
+    inserts = [
+        (r"^        for i in range\(\d+\):", "before", "_golden_hook.dump(-1)"),
+        (r"^            print\('   ',num_collisions_per_step\.value,' collisions from this timestep'\)", "after",
+         "_golden_hook.dump(i, num_collisions_per_step.value, [completed_paths])"),
+        (r"^        print\('Num of measured full paths total: '", "after",
+         "_golden_hook.finish([completed_paths, completed_x_paths, completed_y_paths, completed_z_paths], "
+         "dict(dt=dt, collision_range=collision_range, total_cols=total_cols))"),
+    ]
+    run_patched("Open_Air_Pore_MC.py", subs, inserts, set(snaps) | {-1},
+                f"step_pore_{tag}.npz", dict(K=K, sigma_mult=sigma_mult, slice=slice_, steps=steps))
+
+
+def gen_cube(tag, K, sigma_mult, steps, snaps):
+    subs = [
+        (r"^num_molecules\s+= np\.round\(", f"num_molecules       = np.int64({K})"),
+        (r"^sigma\s+= 3\.6", f"sigma               = 3.6 * 10**(-19) * {sigma_mult}"),
+        (r"^    for i in range\(num_timesteps\):", f"    for i in range({steps}):"),
+    ]
+    inserts = [
+        (r"^    for i in range\(\d+\):", "before", "_step = -1\n_golden_hook.dump(-1)"),
+        (r"^        print\('  timestep',i,'of',num_timesteps", "before", "_step += 1"),
+        (r"^        print\('    ',N_collisions,' collisions'\)", "after",
+         "_golden_hook.dump(_step, N_collisions, [completed_paths[sim]])"),
+        (r"^    #generate figure for graphing", "before",
+         "_golden_hook.finish([completed_paths[sim], completed_x_paths[sim], completed_y_paths[sim], "
+         "completed_z_paths[sim]], dict(dt=dt, collision_range=collision_range))\nraise SystemExit(0)"),
+    ]
+    run_patched("Open_Air_Cube_MC.py", subs, inserts, set(snaps) | {-1},
+                f"step_cube_{tag}.npz", dict(K=K, sigma_mult=sigma_mult, steps=steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    if a.only in ("all", "consts"):
+        gen_consts()
+    if a.only in ("all", "func"):
+        gen_func()
+    if a.only in ("all", "cube"):
+        gen_cube("a", K=6000, sigma_mult=4, steps=40, snaps=[0, 1, 5, 20, 39])
+        gen_cube("dense", K=2500, sigma_mult=36, steps=25, snaps=[0, 1, 10, 24])
+    if a.only in ("all", "pore"):
+        gen_pore("a", K=1500, sigma_mult=100, slice_=1, steps=40, snaps=[0, 1, 5, 20, 39])
+
+
+if __name__ == "__main__":
+    main()

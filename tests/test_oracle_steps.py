@@ -1,0 +1,83 @@
+"""Step-level: the oracle free-runs from the reference's initial state and must reproduce the reference's state
+snapshots, per-step collision counters and completed-path lists BIT FOR BIT (tests/golden/step_*.npz are dumps of
+patched temporary copies of the reference scripts, see oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from argon_monte_carlo_amd import params as PR
+from oracle import oracle as O
+
+STATE_KEYS = ["x_vals", "y_vals", "z_vals", "x_velocities", "y_velocities", "z_velocities", "dist_since_collision",
+              "dist_x_since_collision", "dist_y_since_collision", "dist_z_since_collision", "full_path_traveled"]
+
+
+def load(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path)
+
+
+def make_params(G, kind):
+    K = int(G["meta_K"])
+    sm = float(G["meta_sigma_mult"])
+    sigma = 3.6 * 10**(-19) * sm
+    if kind == "cube":
+        p, c = PR.cube_params(n=K, sigma=sigma)
+    else:
+        p, c = PR.pore_params(n=K, sigma=sigma)
+    assert p.collision_range == float(G["collision_range"])
+    return p, float(G["dt"])
+
+
+def run_and_check(G, kind, mode="pow"):
+    p, dt = make_params(G, kind)
+    o = O.Oracle(p, mode=mode)
+    init = [G[f"s-001_{k}"] for k in STATE_KEYS]
+    o.upload(*init[:10], flag=init[10])
+    per = G["per_step"]
+    nsteps = per.shape[0]
+    snaps = sorted({int(k[1:5]) for k in G.files if k.startswith("s0")})
+    total_paths = 0
+    for s in range(nsteps):
+        rc, st = o.timestep(dt)
+        assert rc == 0
+        ncoll_ref = int(per[s, 1])
+        assert st["n_pp"] + st["n_wall"] == ncoll_ref, (s, st, ncoll_ref)
+        total_paths += st["n_paths"]
+        assert total_paths == int(per[s, 2]), (s, total_paths, per[s, 2])
+        if s in snaps:
+            cur = o.state()
+            for k, f in zip(STATE_KEYS[:10], O.STATE_FIELDS):
+                assert np.array_equal(cur[f], G[f"s{s:04d}_{k}"]), (s, k)
+            assert np.array_equal(cur["flag"].astype(bool), G[f"s{s:04d}_full_path_traveled"].astype(bool))
+    return o
+
+
+@pytest.mark.parametrize("name", ["step_cube_a.npz", "step_cube_dense.npz"])
+def test_cube_free_run_bit_exact(golden_dir, name):
+    G = load(golden_dir, name)
+    o = run_and_check(G, "cube")
+    r = o.paths()
+    # Cube is serial: the completed-path lists are in a deterministic order
+    assert np.array_equal(r["total"], G["completed_paths"])
+    assert np.array_equal(r["px"], G["completed_x_paths"])
+    assert np.array_equal(r["py"], G["completed_y_paths"])
+    assert np.array_equal(r["pz"], G["completed_z_paths"])
+
+
+@pytest.mark.parametrize("name", ["step_pore_a.npz"])
+def test_pore_free_run_bit_exact(golden_dir, name):
+    G = load(golden_dir, name)
+    o = run_and_check(G, "pore")
+    r = o.paths()
+    # Pore appends through Manager().list from worker processes: the order of cells inside one colour group is
+    # scheduling dependent in the reference, so compare the 4-column rows as a multiset
+    got = np.stack([r["total"], r["px"], r["py"], r["pz"]], axis=1)
+    exp = np.stack([G["completed_paths"], G["completed_x_paths"], G["completed_y_paths"], G["completed_z_paths"]], axis=1)
+    assert got.shape == exp.shape
+    gs = got[np.lexsort(got.T[::-1])]
+    es = exp[np.lexsort(exp.T[::-1])]
+    assert np.array_equal(gs, es)
