@@ -1,0 +1,93 @@
+"""Loader of libargonmc.so (the HIP/gfx950 C-ABI library, include/argonmc.h).
+
+There is deliberately no fallback: if the library is missing or no MI355X is usable, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from ._abi import (AMC_ABI_VERSION, AmcDeviceView, AmcParams, AmcPathRecord, AmcStepStats)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libargonmc.so")
+_LIB = None
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_ctx = C.c_void_p
+
+# every symbol include/argonmc.h declares: (restype, argtypes)
+SIGNATURES = {
+    "amc_abi_version": (C.c_int, []),
+    "amc_create": (C.c_int, [C.POINTER(_ctx), C.POINTER(AmcParams)]),
+    "amc_destroy": (None, [_ctx]),
+    "amc_last_error": (C.c_char_p, [_ctx]),
+    "amc_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "amc_synchronize": (C.c_int, [_ctx]),
+    "amc_upload": (C.c_int, [_ctx] + [_dp] * 10 + [_u8p]),
+    "amc_download": (C.c_int, [_ctx] + [_dp] * 10 + [_u8p]),
+    "amc_download_prior": (C.c_int, [_ctx, _dp, _dp, _dp]),
+    "amc_timestep": (C.c_int, [_ctx, C.c_double, C.POINTER(AmcStepStats)]),
+    "amc_run": (C.c_int, [_ctx, C.c_double, C.c_int64, C.POINTER(AmcStepStats)]),
+    "amc_stage_drift": (C.c_int, [_ctx, C.c_double]),
+    "amc_stage_walls": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
+    "amc_stage_bounds": (C.c_int, [_ctx, _i64p]),
+    "amc_stage_sweep": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
+    "amc_pairwise_cell": (C.c_int, [_ctx, C.c_int64] + [_dp] * 4 + [_u8p] + [_dp] * 6 + [_dp, C.c_size_t,
+                                                                                       C.POINTER(C.c_size_t), _i64p]),
+    "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),
+    "amc_drain_paths": (C.c_int, [_ctx, C.POINTER(AmcPathRecord), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_paths_pending": (C.c_int, [_ctx, C.POINTER(C.c_size_t)]),
+    "amc_histograms": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "amc_reset_outputs": (C.c_int, [_ctx]),
+    "amc_set_shard": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
+    "amc_device_view_get": (C.c_int, [_ctx, C.c_int, C.POINTER(AmcDeviceView)]),
+    "amc_mg_local": (C.c_int, [_ctx, C.c_double]),
+    "amc_mg_detect_pack": (C.c_int, [_ctx, _i64p]),
+    "amc_mg_resolve": (C.c_int, [_ctx, C.c_int, _i64p, C.POINTER(AmcStepStats)]),
+    "amc_mg_finish": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
+    "amc_profile": (C.c_int, [_ctx, C.c_int]),
+    "amc_kernel_times": (C.c_int, [_ctx, _dp, _i64p]),
+    "amc_kernel_name": (C.c_char_p, [C.c_int]),
+}
+
+
+class ArgonMCError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libargonmc error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose=False):
+    """Compile libargonmc.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    if verbose or r.returncode != 0:
+        print(r.stdout.decode(errors="replace")[-4000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libargonmc.so failed")
+    return LIB_PATH
+
+
+def load():
+    """dlopen libargonmc.so and type every entry point.  Raises if the library is absent — there is no CPU path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ArgonMCError(-2, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = missing export
+        fn.restype = res
+        fn.argtypes = args
+    if lib.amc_abi_version() != AMC_ABI_VERSION:
+        raise ArgonMCError(-1, "ABI version mismatch between _abi.py and libargonmc.so")
+    _LIB = lib
+    return lib

@@ -1,0 +1,640 @@
+// amc_api.hip — the C ABI of libargonmc.so (include/argonmc.h): context, HBM allocation, upload/download, the
+// timestep driver and measurement helpers.  No CPU compute path exists here: without a HIP device amc_create fails.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "amc_internal.h"
+
+int amc_fail(amc_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+static thread_local std::string g_create_err;
+
+// ---- profiling brackets ---------------------------------------------------------------------------------------------
+void amc_prof_begin(amc_ctx *c, int kclass)
+{
+    if (!c->profiling) return;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        c->ev_pool.push_back({a, b});
+    }
+    c->ev_pending.push_back({kclass, (int)c->ev_used});
+    hipEventRecord(c->ev_pool[c->ev_used].first, c->stream);
+}
+void amc_prof_end(amc_ctx *c)
+{
+    if (!c->profiling) return;
+    hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    c->ev_used++;
+    if (c->ev_used >= 4096) amc_prof_collect(c);
+}
+void amc_prof_collect(amc_ctx *c)
+{
+    if (!c->profiling || c->ev_pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto &pr : c->ev_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[pr.second].first, c->ev_pool[pr.second].second) == hipSuccess) {
+            c->k_ms[pr.first] += ms;
+            c->k_launches[pr.first]++;
+        }
+    }
+    c->ev_pending.clear();
+    c->ev_used = 0;
+}
+
+// ---- helpers ------------------------------------------------------------------------------------------------------------
+template <class T>
+static hipError_t dalloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    return hipMalloc((void **)p, sizeof(T) * count);
+}
+
+static int next_pow2(int v)
+{
+    int m = 1;
+    while (m < v) m <<= 1;
+    return m;
+}
+
+// detection grid: uniform cells, per-layer square window (full extent in the open-air end caps, gap radius inside
+// the pore body); Cube: one window for all layers
+static int setup_grid(amc_ctx *c)
+{
+    const amc_params &P = c->P;
+    amc_grid &G = c->G;
+    memset(&G, 0, sizeof G);
+    if (c->allpairs) return AMC_OK;
+    const double cr = P.collision_range;
+    double xlo, xhi, zlo, zhi, volume;
+    if (P.geometry == AMC_GEOM_CUBE) {
+        xlo = 0; xhi = std::max(P.cube_x, P.cube_y); zlo = 0; zhi = P.cube_z;
+        volume = P.cube_x * P.cube_y * P.cube_z;
+    } else {
+        xlo = -P.R_oa; xhi = P.R_oa; zlo = 0; zhi = P.H;
+        const double pi = 3.14159265358979323846;
+        volume = 2 * pi * P.R_oa * P.R_oa * P.h_oa + pi * P.R_g * P.R_g * (P.H - 2 * P.h_oa);
+    }
+    double h = P.fine_cell;
+    if (!(h > 0)) {
+        const double spacing = cbrt(volume / (double)std::max<int64_t>(1, c->n));
+        h = std::max(spacing, 1.25 * cr);
+    }
+    if (h < 1.0000001 * cr) return amc_fail(c, AMC_ERR_INVALID, "fine_cell %g must exceed collision_range %g", h, cr);
+    // keep the table bounded
+    for (;;) {
+        const double nxy = ceil((xhi - xlo) / h) + 2, nz = ceil((zhi - zlo) / h) + 2;
+        if (nxy * nxy * nz < 2.0e8) break;
+        h *= 1.26;
+    }
+    G.h = h;
+    G.x0 = xlo - h; G.y0 = xlo - h; G.z0 = zlo - h;           // one guard cell on every side
+    G.gx = G.gy = (int)ceil((xhi - xlo) / h) + 2;
+    G.gz = (int)ceil((zhi - zlo) / h) + 2;
+    c->h_lay_lo.assign(G.gz, 0);
+    c->h_lay_n.assign(G.gz, G.gx);
+    c->h_lay_off.assign(G.gz, 0);
+    if (P.geometry != AMC_GEOM_CUBE) {
+        // pore body layers only need |x|,|y| <= R_g (+ one guard cell); layers touching the end caps keep the full disc
+        const double body_lo = P.h_oa + h + cr, body_hi = P.z_cold - h - cr;
+        const int w_lo = std::max(0, (int)floor((-P.R_g - cr - G.x0) / h) - 1);
+        const int w_hi = std::min(G.gx - 1, (int)floor((P.R_g + cr - G.x0) / h) + 1);
+        for (int k = 0; k < G.gz; k++) {
+            const double z_a = G.z0 + k * h, z_b = z_a + h;
+            if (z_a > body_lo && z_b < body_hi) { c->h_lay_lo[k] = w_lo; c->h_lay_n[k] = w_hi - w_lo + 1; }
+        }
+    }
+    long long off = 0;
+    for (int k = 0; k < G.gz; k++) {
+        c->h_lay_off[k] = (int)off;
+        off += (long long)c->h_lay_n[k] * c->h_lay_n[k];
+    }
+    if (off > 0x7fff0000LL) return amc_fail(c, AMC_ERR_INVALID, "detection grid too large (%lld cells)", off);
+    G.ncells = (int)off;
+    AMC_HIP(c, dalloc(&c->d_lay, (size_t)3 * G.gz));
+    AMC_HIP(c, hipMemcpy(c->d_lay, c->h_lay_lo.data(), sizeof(int) * G.gz, hipMemcpyHostToDevice));
+    AMC_HIP(c, hipMemcpy(c->d_lay + G.gz, c->h_lay_n.data(), sizeof(int) * G.gz, hipMemcpyHostToDevice));
+    AMC_HIP(c, hipMemcpy(c->d_lay + 2 * G.gz, c->h_lay_off.data(), sizeof(int) * G.gz, hipMemcpyHostToDevice));
+    G.lay_lo = c->d_lay; G.lay_n = c->d_lay + G.gz; G.lay_off = c->d_lay + 2 * G.gz;
+    return AMC_OK;
+}
+
+extern "C" {
+
+int amc_abi_version(void) { return AMC_ABI_VERSION; }
+
+const char *amc_last_error(const amc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+const char *amc_kernel_name(int k)
+{
+    static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan", "bin_scatter",
+                                             "detect",      "resolve",   "bounds",   "other"};
+    return (k >= 0 && k < AMC_K_COUNT) ? names[k] : "?";
+}
+
+void amc_destroy(amc_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
+                    c->S.pz, c->S.flag, c->d_lay, c->B.sx, c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, c->B.cell_count,
+                    c->B.cid, c->B.rank, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
+                    c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
+                    c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
+                    c->W.edge_b, c->W.hist_slot, c->W.hist_x, c->W.hist_y, c->W.hist_z, c->W.ov_head, c->W.ov_next,
+                    c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
+                    c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int amc_create(amc_ctx **out, const amc_params *p)
+{
+    if (!out || !p) { g_create_err = "null argument"; return AMC_ERR_INVALID; }
+    *out = nullptr;
+    if (p->struct_size != (int32_t)sizeof(amc_params)) {
+        g_create_err = "amc_params.struct_size mismatch (ABI)";
+        return AMC_ERR_INVALID;
+    }
+    if (p->n < 0 || p->n > 0x7fffffffLL || !(p->collision_range > 0) || !(p->argon_mass > 0) || p->geometry < 0 ||
+        p->geometry > AMC_GEOM_PORE_ENERGISED) {
+        g_create_err = "invalid amc_params (n, collision_range, argon_mass or geometry)";
+        return AMC_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) {
+        g_create_err = "no usable HIP device (libargonmc has no CPU fallback)";
+        return AMC_ERR_NO_DEVICE;
+    }
+    amc_ctx *c = new (std::nothrow) amc_ctx();
+    if (!c) { g_create_err = "out of host memory"; return AMC_ERR_INVALID; }
+    c->P = *p;
+    c->device = p->device;
+    c->n = p->n; c->lo = 0; c->hi = p->n;
+    c->uploaded = false;
+    c->keep_prior = (p->reserved0 & 1) != 0;
+    c->profiling = false;
+    c->ev_used = 0;
+    memset(c->k_ms, 0, sizeof c->k_ms);
+    memset(c->k_launches, 0, sizeof c->k_launches);
+    memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
+    memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
+    c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
+    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
+    c->stream = nullptr;
+    int rc = AMC_OK;
+#define CK(call)                                                                                       \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            rc = amc_fail(c, AMC_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__));             \
+            goto fail;                                                                                 \
+        }                                                                                              \
+    } while (0)
+    {
+        CK(hipSetDevice(c->device));
+        CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        const size_t n = (size_t)c->n;
+        // detection mode: single cells and small N use the LDS-tiled all-pairs kernel
+        c->allpairs = (p->geometry == AMC_GEOM_CELL) || p->detect_mode == 2 || (p->detect_mode == 0 && c->n <= 4096);
+        if (p->geometry == AMC_GEOM_CELL && p->detect_mode == 1) {
+            rc = amc_fail(c, AMC_ERR_INVALID, "AMC_GEOM_CELL has no cell grid: detect_mode must be 0 or 2");
+            goto fail;
+        }
+        double **st[] = {&c->S.x, &c->S.y, &c->S.z, &c->S.vx, &c->S.vy, &c->S.vz, &c->S.d, &c->S.dx, &c->S.dy, &c->S.dz,
+                         &c->S.px, &c->S.py, &c->S.pz};
+        for (auto pp : st) { CK(dalloc(pp, n)); CK(hipMemsetAsync(*pp, 0, sizeof(double) * std::max<size_t>(n, 1), c->stream)); }
+        CK(dalloc(&c->S.flag, n));
+        CK(hipMemsetAsync(c->S.flag, 0, std::max<size_t>(n, 1), c->stream));
+        if ((rc = setup_grid(c)) != AMC_OK) goto fail;
+        if (!c->allpairs) {
+            const size_t nc = (size_t)c->G.ncells;
+            CK(dalloc(&c->B.sx, n)); CK(dalloc(&c->B.sy, n)); CK(dalloc(&c->B.sz, n)); CK(dalloc(&c->B.sidx, n));
+            CK(dalloc(&c->B.cid, n)); CK(dalloc(&c->B.rank, n));
+            CK(dalloc(&c->B.cell_start, nc + 1)); CK(dalloc(&c->B.cell_count, nc + 1));
+            c->scan_blocks = (int)((nc + 4095) / 4096);
+            CK(dalloc(&c->scan_tmp, (size_t)c->scan_blocks + 1));
+            CK(dalloc(&c->W.ov_head, nc));
+            CK(hipMemsetAsync(c->W.ov_head, 0xff, sizeof(int) * std::max<size_t>(nc, 1), c->stream));
+        }
+        // resolve work space
+        amc_resolve_ws &W = c->W;
+        long long mc = p->max_candidates > 0 ? p->max_candidates : std::max<long long>(4096, c->n / 8 + 1024);
+        if (mc > 0x3fffffff) mc = 0x3fffffff;
+        W.max_cand = (int)mc;
+        W.max_slots = (int)std::min<long long>(2 * mc, std::max<long long>(c->n, 2));
+        W.max_edges = 4 * W.max_slots + 1024;
+        W.max_hist = 8 * W.max_slots + 1024;
+        W.max_events = 8 * W.max_slots + 1024;
+        CK(dalloc(&W.cand_i, (size_t)W.max_cand)); CK(dalloc(&W.cand_j, (size_t)W.max_cand));
+        CK(dalloc(&W.slot_of, n));
+        CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));
+        const size_t ms = (size_t)W.max_slots;
+        CK(dalloc(&W.sl_p, ms)); CK(dalloc(&W.sl_label, ms)); CK(dalloc(&W.sl_tmp, ms)); CK(dalloc(&W.order, ms));
+        CK(dalloc(&W.sl_key, (size_t)next_pow2(W.max_slots)));
+        double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
+        for (auto pp : sl) CK(dalloc(pp, ms));
+        CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms));
+        CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
+        CK(dalloc(&W.hist_slot, (size_t)W.max_hist)); CK(dalloc(&W.hist_x, (size_t)W.max_hist));
+        CK(dalloc(&W.hist_y, (size_t)W.max_hist)); CK(dalloc(&W.hist_z, (size_t)W.max_hist));
+        CK(dalloc(&W.ov_next, (size_t)W.max_hist));
+        CK(dalloc(&W.ev_phase, (size_t)W.max_events)); CK(dalloc(&W.ev_i, (size_t)W.max_events));
+        CK(dalloc(&W.ev_j, (size_t)W.max_events)); CK(dalloc(&W.ev_which, (size_t)W.max_events));
+        CK(dalloc(&W.ev_cell, (size_t)W.max_events)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_events));
+        // outputs
+        long long mp = p->max_paths > 0 ? p->max_paths : (1LL << 20);
+        if (mp > 0x7fffffff) mp = 0x7fffffff;
+        CK(dalloc(&c->d_rec, (size_t)mp));
+        CK(dalloc(&c->d_cnt, 1));
+        CK(hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
+        c->out.rec = c->d_rec; c->out.cap = (unsigned)mp; c->out.cnt = c->d_cnt;
+        c->out.nbins = 0; c->out.hist = nullptr; c->out.edges = nullptr; c->out.lo = p->hist_lo; c->out.hi = p->hist_hi;
+        if (p->hist_bins > 0 && p->hist_hi > p->hist_lo) {
+            const int nb = p->hist_bins;
+            CK(dalloc(&c->d_hist, (size_t)4 * nb));
+            CK(hipMemsetAsync(c->d_hist, 0, sizeof(unsigned long long) * 4 * nb, c->stream));
+            CK(dalloc(&c->d_edges, (size_t)nb + 1));
+            // np.linspace(lo, hi, nb+1): start + k*step with step = (hi-lo)/nb, last element forced to hi
+            std::vector<double> ed(nb + 1);
+            const double step = (p->hist_hi - p->hist_lo) / (double)nb;
+            for (int k = 0; k <= nb; k++) ed[k] = p->hist_lo + (double)k * step;
+            ed[nb] = p->hist_hi;
+            CK(hipMemcpy(c->d_edges, ed.data(), sizeof(double) * (nb + 1), hipMemcpyHostToDevice));
+            c->out.nbins = nb; c->out.hist = c->d_hist; c->out.edges = c->d_edges;
+        }
+        CK(hipStreamSynchronize(c->stream));
+    }
+#undef CK
+    *out = c;
+    return AMC_OK;
+fail:
+    g_create_err = c->err;
+    amc_destroy(c);
+    return rc;
+}
+
+int amc_set_stream(amc_ctx *c, void *hip_stream)
+{
+    if (!c) return AMC_ERR_INVALID;
+    hipSetDevice(c->device);
+    amc_prof_collect(c);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AMC_OK;
+}
+
+int amc_synchronize(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+int amc_upload(amc_ctx *c, const double *x, const double *y, const double *z, const double *vx, const double *vy,
+               const double *vz, const double *dist, const double *dist_x, const double *dist_y, const double *dist_z,
+               const uint8_t *full_path)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * (size_t)c->n;
+    const double *src[] = {x, y, z, vx, vy, vz, dist, dist_x, dist_y, dist_z};
+    double *dst[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz};
+    for (int k = 0; k < 10; k++)
+        if (src[k] && nb) AMC_HIP(c, hipMemcpyAsync(dst[k], src[k], nb, hipMemcpyHostToDevice, c->stream));
+    if (full_path && c->n) AMC_HIP(c, hipMemcpyAsync(c->S.flag, full_path, (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    return AMC_OK;
+}
+
+int amc_download(amc_ctx *c, double *x, double *y, double *z, double *vx, double *vy, double *vz, double *dist,
+                 double *dist_x, double *dist_y, double *dist_z, uint8_t *full_path)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * (size_t)c->n;
+    double *dst[] = {x, y, z, vx, vy, vz, dist, dist_x, dist_y, dist_z};
+    double *src[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz};
+    for (int k = 0; k < 10; k++)
+        if (dst[k] && nb) AMC_HIP(c, hipMemcpyAsync(dst[k], src[k], nb, hipMemcpyDeviceToHost, c->stream));
+    if (full_path && c->n) AMC_HIP(c, hipMemcpyAsync(full_path, c->S.flag, (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+int amc_download_prior(amc_ctx *c, double *px, double *py, double *pz)
+{
+    if (!c) return AMC_ERR_INVALID;
+    if (!c->keep_prior) return amc_fail(c, AMC_ERR_STATE, "prior_*_vals are only kept when amc_params.reserved0 bit0 is set");
+    AMC_HIP(c, hipSetDevice(c->device));
+    const size_t nb = sizeof(double) * (size_t)c->n;
+    if (px && nb) AMC_HIP(c, hipMemcpyAsync(px, c->S.px, nb, hipMemcpyDeviceToHost, c->stream));
+    if (py && nb) AMC_HIP(c, hipMemcpyAsync(py, c->S.py, nb, hipMemcpyDeviceToHost, c->stream));
+    if (pz && nb) AMC_HIP(c, hipMemcpyAsync(pz, c->S.pz, nb, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+// ---- the step ----------------------------------------------------------------------------------------------------------
+static int read_counters(amc_ctx *c, amc_dev_counters *h)
+{
+    AMC_HIP(c, hipMemcpyAsync(h, c->d_cnt, sizeof *h, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+static void delta_stats(const amc_dev_counters &now, const amc_dev_counters &prev, amc_step_stats *o)
+{
+    o->n_pp = (int64_t)(now.n_pp - prev.n_pp);
+    o->n_wall = (int64_t)(now.n_wall - prev.n_wall);
+    o->n_oob_walls = (int64_t)(now.n_oob_walls - prev.n_oob_walls);
+    o->n_oob_pp = (int64_t)(now.n_oob_pp - prev.n_oob_pp);
+    o->n_paths = (int64_t)(now.n_paths - prev.n_paths);
+    o->n_candidates = (int64_t)(now.n_candidates - prev.n_candidates);
+    o->n_clusters = (int64_t)(now.n_clusters - prev.n_clusters);
+    o->n_rounds = (int64_t)(now.n_rounds - prev.n_rounds);
+    o->n_fp_errors = (int64_t)(now.n_fp_errors - prev.n_fp_errors);
+    o->flags = (int64_t)now.flags;
+}
+
+static int finish_stats(amc_ctx *c, amc_step_stats *out)
+{
+    amc_dev_counters now;
+    int rc = read_counters(c, &now);
+    if (rc) return rc;
+    amc_step_stats st;
+    delta_stats(now, c->h_prev, &st);
+    c->h_prev = now;
+    if (out) *out = st;
+    if (now.flags & 7ULL) {
+        const unsigned long long f = now.flags;
+        // clear the sticky flags on the device so that a later call can succeed after the caller drained / resized
+        unsigned long long zero = 0;
+        hipMemcpyAsync(&c->d_cnt->flags, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream);
+        hipStreamSynchronize(c->stream);
+        c->h_prev.flags = 0;
+        return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 2 path records, 4 resolve)", f);
+    }
+    if (st.n_fp_errors > 0 && c->P.geometry != AMC_GEOM_PORE_ENERGISED)
+        return amc_fail(c, AMC_ERR_FP, "%lld event(s) where the reference raises FloatingPointError", (long long)st.n_fp_errors);
+    return AMC_OK;
+}
+
+static int enqueue_sweep(amc_ctx *c)
+{
+    AMC_HIP(c, amc_launch_bin(c));
+    AMC_HIP(c, amc_launch_detect(c));
+    AMC_HIP(c, amc_launch_resolve(c));
+    return AMC_OK;
+}
+
+static __global__ void k_next_step(amc_dev_counters *cnt) { cnt->step += 1; }
+
+static int enqueue_step(amc_ctx *c, double dt)
+{
+    const int g = c->P.geometry;
+    int rc;
+    if (g == AMC_GEOM_CELL) {
+        if ((rc = enqueue_sweep(c))) return rc;
+    } else if (g == AMC_GEOM_CUBE) {
+        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
+        if ((rc = enqueue_sweep(c))) return rc;
+    } else if (g == AMC_GEOM_PORE) {
+        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS, 0));
+        if ((rc = enqueue_sweep(c))) return rc;
+        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
+    } else {
+        return amc_fail(c, AMC_ERR_INVALID, "energised walls need the host handshake: use the Python driver (amc_wall_hits/apply)");
+    }
+    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    return AMC_OK;
+}
+
+int amc_timestep(amc_ctx *c, double dt, amc_step_stats *out)
+{
+    if (!c) return AMC_ERR_INVALID;
+    if (!c->uploaded) return amc_fail(c, AMC_ERR_STATE, "amc_timestep before amc_upload");
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_step(c, dt);
+    if (rc) return rc;
+    return finish_stats(c, out);
+}
+
+int amc_run(amc_ctx *c, double dt, int64_t nsteps, amc_step_stats *sum)
+{
+    if (!c) return AMC_ERR_INVALID;
+    if (!c->uploaded) return amc_fail(c, AMC_ERR_STATE, "amc_run before amc_upload");
+    AMC_HIP(c, hipSetDevice(c->device));
+    for (int64_t s = 0; s < nsteps; s++) {
+        int rc = enqueue_step(c, dt);
+        if (rc) return rc;
+    }
+    return finish_stats(c, sum);
+}
+
+int amc_stage_drift(amc_ctx *c, double dt)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    const bool kp = c->keep_prior;
+    c->keep_prior = true;       // a following amc_stage_walls needs prior_*_vals
+    hipError_t e = amc_launch_stream(c, dt, AMC_ST_DRIFT, 0);
+    c->keep_prior = kp;
+    AMC_HIP(c, e);
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+int amc_stage_walls(amc_ctx *c, amc_step_stats *out)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_WALLS, 0));
+    return finish_stats(c, out);
+}
+
+int amc_stage_bounds(amc_ctx *c, int64_t *n_moved)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));
+    amc_step_stats st;
+    int rc = finish_stats(c, &st);
+    if (n_moved) *n_moved = st.n_oob_walls;
+    return rc;
+}
+
+int amc_stage_sweep(amc_ctx *c, amc_step_stats *out)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = enqueue_sweep(c);
+    if (rc) return rc;
+    return finish_stats(c, out);
+}
+
+// ---- outputs ----------------------------------------------------------------------------------------------------------
+int amc_paths_pending(amc_ctx *c, size_t *n)
+{
+    if (!c || !n) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_dev_counters now;
+    int rc = read_counters(c, &now);
+    if (rc) return rc;
+    *n = std::min<size_t>(now.path_count, c->out.cap);
+    return AMC_OK;
+}
+
+int amc_drain_paths(amc_ctx *c, amc_path_record *out, size_t cap, size_t *n)
+{
+    if (!c || !n) return AMC_ERR_INVALID;
+    size_t pending;
+    int rc = amc_paths_pending(c, &pending);
+    if (rc) return rc;
+    if (pending > cap) return amc_fail(c, AMC_ERR_CAPACITY, "amc_drain_paths: %zu records pending, buffer holds %zu", pending, cap);
+    if (pending) AMC_HIP(c, hipMemcpyAsync(out, c->d_rec, sizeof(amc_path_record) * pending, hipMemcpyDeviceToHost, c->stream));
+    unsigned int zero = 0;
+    AMC_HIP(c, hipMemcpyAsync(&c->d_cnt->path_count, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    *n = pending;
+    return AMC_OK;
+}
+
+int amc_histograms(amc_ctx *c, uint64_t *counts, uint64_t *n_paths_total)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (counts) {
+        if (!c->d_hist) return amc_fail(c, AMC_ERR_STATE, "histograms disabled (hist_bins == 0)");
+        AMC_HIP(c, hipMemcpyAsync(counts, c->d_hist, sizeof(uint64_t) * 4 * c->out.nbins, hipMemcpyDeviceToHost, c->stream));
+    }
+    amc_dev_counters now;
+    int rc = read_counters(c, &now);
+    if (rc) return rc;
+    if (n_paths_total) *n_paths_total = now.n_paths_total;
+    return AMC_OK;
+}
+
+int amc_reset_outputs(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (c->d_hist) AMC_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(uint64_t) * 4 * c->out.nbins, c->stream));
+    AMC_HIP(c, hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    memset(&c->h_prev, 0, sizeof c->h_prev);
+    return AMC_OK;
+}
+
+// ---- pairwise_particles_in_cell replacement ---------------------------------------------------------------------------
+int amc_pairwise_cell(amc_ctx *c, int64_t n_cell, double *continue_path, double *continue_x_path, double *continue_y_path,
+                      double *continue_z_path, uint8_t *has_collided, double *x, double *y, double *z, double *vx,
+                      double *vy, double *vz, double *out_paths, size_t cap, size_t *n_paths, int64_t *n_collisions)
+{
+    if (!c) return AMC_ERR_INVALID;
+    if (c->P.geometry != AMC_GEOM_CELL) return amc_fail(c, AMC_ERR_STATE, "amc_pairwise_cell needs an AMC_GEOM_CELL context");
+    if (n_cell < 0 || n_cell > c->n) return amc_fail(c, AMC_ERR_INVALID, "n_cell %lld exceeds the context capacity %lld", (long long)n_cell, (long long)c->n);
+    AMC_HIP(c, hipSetDevice(c->device));
+    // the context is sized for its capacity; run on the first n_cell entries
+    const int64_t n_full = c->n;
+    c->n = n_cell; c->lo = 0; c->hi = n_cell;
+    int rc = amc_upload(c, x, y, z, vx, vy, vz, continue_path, continue_x_path, continue_y_path, continue_z_path, has_collided);
+    amc_step_stats st;
+    memset(&st, 0, sizeof st);
+    size_t pending = 0;
+    if (!rc) {
+        size_t dummy;
+        rc = amc_paths_pending(c, &dummy);          // discard nothing: records of earlier calls were drained by them
+    }
+    if (!rc) rc = amc_timestep(c, 0.0, &st);
+    if (!rc) rc = amc_download(c, x, y, z, vx, vy, vz, continue_path, continue_x_path, continue_y_path, continue_z_path, has_collided);
+    if (!rc) rc = amc_paths_pending(c, &pending);
+    if (!rc && pending) {
+        std::vector<amc_path_record> rec(pending);
+        size_t got = 0;
+        rc = amc_drain_paths(c, rec.data(), pending, &got);
+        if (!rc) {
+            // the reference appends in loop order: i ascending, j ascending, particle j before particle i
+            std::sort(rec.begin(), rec.begin() + got, [](const amc_path_record &a, const amc_path_record &b) {
+                if (a.step != b.step) return a.step < b.step;
+                if (a.i != b.i) return a.i < b.i;
+                if (a.j != b.j) return a.j < b.j;
+                return a.which < b.which;
+            });
+            if (got > cap) rc = amc_fail(c, AMC_ERR_CAPACITY, "out_paths holds %zu paths, %zu were completed", cap, got);
+            else if (out_paths)
+                for (size_t k = 0; k < got; k++) {
+                    out_paths[0 * cap + k] = rec[k].total; out_paths[1 * cap + k] = rec[k].px;
+                    out_paths[2 * cap + k] = rec[k].py; out_paths[3 * cap + k] = rec[k].pz;
+                }
+            pending = got;
+        }
+    }
+    if (n_paths) *n_paths = pending;
+    if (n_collisions) *n_collisions = st.n_pp;
+    c->n = n_full; c->lo = 0; c->hi = n_full;
+    return rc;
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------------------
+int amc_profile(amc_ctx *c, int enable)
+{
+    if (!c) return AMC_ERR_INVALID;
+    hipSetDevice(c->device);
+    amc_prof_collect(c);
+    c->profiling = enable != 0;
+    return AMC_OK;
+}
+
+int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
+{
+    if (!c) return AMC_ERR_INVALID;
+    hipSetDevice(c->device);
+    amc_prof_collect(c);
+    for (int k = 0; k < AMC_K_COUNT; k++) {
+        if (total_ms) total_ms[k] = c->k_ms[k];
+        if (launches) launches[k] = c->k_launches[k];
+    }
+    return AMC_OK;
+}
+
+// ---- not yet available in this build ----------------------------------------------------------------------------------
+int amc_wall_hits(amc_ctx *c, int, int32_t *, double *, double *, size_t, size_t *) { return amc_fail(c, AMC_ERR_INVALID, "energised walls: not implemented yet"); }
+int amc_wall_apply(amc_ctx *c, int, const double *, const double *, size_t, double *, double *) { return amc_fail(c, AMC_ERR_INVALID, "energised walls: not implemented yet"); }
+int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
+{
+    if (!c || lo < 0 || hi < lo || hi > c->n) return AMC_ERR_INVALID;
+    c->lo = lo; c->hi = hi;
+    return AMC_OK;
+}
+int amc_device_view_get(amc_ctx *c, int, amc_device_view *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+int amc_mg_local(amc_ctx *c, double) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+int amc_mg_detect_pack(amc_ctx *c, int64_t *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+int amc_mg_resolve(amc_ctx *c, int, const int64_t *, amc_step_stats *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+int amc_mg_finish(amc_ctx *c, amc_step_stats *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// amc_grid.hip — candidate detection for the p-p sweep (the parallel half of Pore:520-549 / Cube:231-336).
+//
+// The reference finds colliding pairs by an O(n^2) loop inside each ~21 nm cell.  Every pair closer than
+// collision_range shares at least one reference cell, so ANY exact close-pair detector produces a
+// superset of the pairs the reference can hit; the ordered resolve (amc_resolve.hip) then re-tests each pair with
+// the reference's own cell membership and loop order.  Two detectors:
+//
+//   binned   : counting sort of the particles into cells of edge h ~ mean spacing (>= collision_range), x fastest,
+//              then a half-stencil search (own row forward + 4 neighbour rows, each a contiguous range of the sorted
+//              arrays).  O(N) work, HBM/L2-bound.  Algorithmic traffic 24 B/particle (positions read once);
+//              the sorted copy (28 B written + read) and the cell tables are implementation overhead.
+//   all-pairs: LDS-tiled j-block (256 particles = 6 KB) against 256 i-particles in registers, upper triangle of
+//              tiles only — the kernel the reference's pairwise_particles_in_cell maps to directly; fp64-VALU-bound
+//              (9 flop per pair), used for single cells (amc_pairwise_cell), small N and cross-validation.
+//
+// A pair is emitted when d^2 < collision_range^2 * (1 + 1e-9): a superset of the reference's
+// `sqrt(d^2) < collision_range` test, which the resolve re-evaluates exactly.
+#include "amc_grid_dev.h"
+
+#define AMC_CR2_INFLATE (1.0 + 1.0e-9)
+
+// ---- binning -----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bin_count(const double *__restrict__ x, const double *__restrict__ y,
+                                                   const double *__restrict__ z, long long n, amc_grid G,
+                                                   int *__restrict__ cell_count, int *__restrict__ cid,
+                                                   int *__restrict__ rank, amc_dev_counters *cnt)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int cx, cy, cz;
+    amc_grid_coords(G, x[p], y[p], z[p], cx, cy, cz);
+    bool outside = false;
+    const int c = amc_grid_cell(G, cx, cy, cz, &outside);
+    if (outside) atomicOr(&cnt->flags, 8ULL);
+    cid[p] = c;
+    rank[p] = atomicAdd(&cell_count[c], 1);
+}
+
+// exclusive scan, three small kernels: per-block scan of 4096 items -> scan of block sums -> add back
+#define SCAN_T 1024
+#define SCAN_ITEMS 4
+#define SCAN_BLOCK (SCAN_T * SCAN_ITEMS)
+
+__device__ inline int block_exclusive_scan_1024(int v, int *total)
+{
+    __shared__ int wsum[SCAN_T / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+        int s = (lane < SCAN_T / 64) ? wsum[lane] : 0;
+        for (int o = 1; o < SCAN_T / 64; o <<= 1) {
+            int t = __shfl_up(s, o, 64);
+            if (lane >= o) s += t;
+        }
+        if (lane < SCAN_T / 64) wsum[lane] = s;
+    }
+    __syncthreads();
+    const int base = (w > 0) ? wsum[w - 1] : 0;
+    if (total) *total = wsum[SCAN_T / 64 - 1];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_block(const int *__restrict__ in, int *__restrict__ out, int n,
+                                                       int *__restrict__ block_sums)
+{
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int total;
+    int ex = block_exclusive_scan_1024(s, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_sums(int *__restrict__ block_sums, int nb, int *__restrict__ out_total)
+{
+    // single block; nb <= SCAN_T * 64 handled by a serial carry over chunks of SCAN_T
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += SCAN_T) {
+        const int i = base + threadIdx.x;
+        const int v = (i < nb) ? block_sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan_1024(v, &total);
+        if (i < nb) block_sums[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, int n, const int *__restrict__ block_sums)
+{
+    const int add = block_sums[blockIdx.x];
+    const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+        if (base + k < n) out[base + k] += add;
+}
+
+__global__ __launch_bounds__(256) void k_bin_scatter(const double *__restrict__ x, const double *__restrict__ y,
+                                                     const double *__restrict__ z, long long n,
+                                                     const int *__restrict__ cid, const int *__restrict__ rank,
+                                                     const int *__restrict__ cell_start, double *__restrict__ sx,
+                                                     double *__restrict__ sy, double *__restrict__ sz,
+                                                     int *__restrict__ sidx)
+{
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int s = cell_start[cid[p]] + rank[p];
+    sx[s] = x[p]; sy[s] = y[p]; sz[s] = z[p];
+    sidx[s] = (int)p;
+}
+
+// ---- binned detection: one thread per sorted particle, half stencil ------------------------------------------------
+AMC_DEV void amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
+{
+    const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
+    if (k < (unsigned)max_cand) {
+        cand_i[k] = a > b ? a : b;
+        cand_j[k] = a > b ? b : a;
+    } else {
+        atomicOr(&cnt->flags, 1ULL);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_detect_binned(amc_grid G, const double *__restrict__ sx,
+                                                       const double *__restrict__ sy, const double *__restrict__ sz,
+                                                       const int *__restrict__ sidx,
+                                                       const int *__restrict__ cell_start, long long n, double cr2i,
+                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
+{
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const double x = sx[s], y = sy[s], z = sz[s];
+    const int me = sidx[s];
+    int cx, cy, cz;
+    amc_grid_coords(G, x, y, z, cx, cy, cz);
+    // rows of the half stencil: (dy,dz) = (0,0) forward part, (1,0), (-1,1), (0,1), (1,1)
+    const int rdy[5] = {0, 1, -1, 0, 1};
+    const int rdz[5] = {0, 0, 1, 1, 1};
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        int c_lo, c_hi;
+        if (!amc_grid_row(G, cx, cy + rdy[r], cz + rdz[r], c_lo, c_hi)) continue;
+        int q0 = cell_start[c_lo];
+        const int q1 = cell_start[c_hi + 1];
+        if (r == 0) q0 = (int)s + 1;       // own row: later entries of my cell and the next cell only
+        for (int q = q0; q < q1; q++) {
+            const double ex = sx[q] - x, ey = sy[q] - y, ez = sz[q] - z;
+            const double d2 = ex * ex + ey * ey + ez * ez;
+            if (d2 < cr2i) amc_push_candidate(me, sidx[q], cand_i, cand_j, max_cand, cnt);
+        }
+    }
+}
+
+// ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
+#define AP_T 256
+__global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
+                                                          const double *__restrict__ z, int n, int ntiles, double cr2i,
+                                                          int *cand_i, int *cand_j, int max_cand,
+                                                          amc_dev_counters *cnt)
+{
+    // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
+    int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long long)(bi + 1) * (bi + 2) / 2 <= (long long)blockIdx.x) bi++;
+    while ((long long)bi * (bi + 1) / 2 > (long long)blockIdx.x) bi--;
+    const int bj = (int)(blockIdx.x - (long long)bi * (bi + 1) / 2);
+    if (bi >= ntiles) return;
+    __shared__ double tx[AP_T], ty[AP_T], tz[AP_T];
+    const int j0 = bj * AP_T;
+    const int jj = j0 + threadIdx.x;
+    tx[threadIdx.x] = (jj < n) ? x[jj] : 0.0;
+    ty[threadIdx.x] = (jj < n) ? y[jj] : 0.0;
+    tz[threadIdx.x] = (jj < n) ? z[jj] : 0.0;
+    __syncthreads();
+    const int i = bi * AP_T + threadIdx.x;
+    if (i >= n) return;
+    const double xi = x[i], yi = y[i], zi = z[i];
+    int jmax = n - j0;
+    if (jmax > AP_T) jmax = AP_T;
+    if (bi == bj && jmax > (int)threadIdx.x) jmax = threadIdx.x;   // j < i inside the diagonal tile
+    for (int k = 0; k < jmax; k++) {
+        const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
+        const double d2 = ex * ex + ey * ey + ez * ez;
+        if (d2 < cr2i) amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt);
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+hipError_t amc_launch_bin(amc_ctx *c)
+{
+    if (c->allpairs) return hipSuccess;
+    const long long n = c->n;
+    const int nc = c->G.ncells;
+    hipError_t e;
+    amc_prof_begin(c, AMC_K_BIN_COUNT);
+    e = hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (size_t)nc, c->stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z, n,
+                       c->G, c->B.cell_count, c->B.cid, c->B.rank, c->d_cnt);
+    amc_prof_end(c);
+    const int nb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    amc_prof_begin(c, AMC_K_BIN_SCAN);
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, c->stream, c->B.cell_count, c->B.cell_start, nc,
+                       c->scan_tmp);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, c->stream, c->scan_tmp, nb, c->B.cell_start + nc);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, c->stream, c->B.cell_start, nc, c->scan_tmp);
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_BIN_SCATTER);
+    hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z,
+                       n, c->B.cid, c->B.rank, c->B.cell_start, c->B.sx, c->B.sy, c->B.sz, c->B.sidx);
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+
+hipError_t amc_launch_detect(amc_ctx *c)
+{
+    const long long n = c->n;
+    const double cr2i = c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE;
+    amc_prof_begin(c, AMC_K_DETECT);
+    if (c->allpairs) {
+        const int ntiles = (int)((n + AP_T - 1) / AP_T);
+        const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
+        if (nblocks > 0)
+            hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
+                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt);
+    } else {
+        hipLaunchKernelGGL(k_detect_binned, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B.sx,
+                           c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, n, cr2i, c->W.cand_i, c->W.cand_j,
+                           c->W.max_cand, c->d_cnt);
+    }
+    amc_prof_end(c);
+    return hipGetLastError();
+}

@@ -1,0 +1,120 @@
+// amc_internal.h — host-side context of libargonmc.so and the launcher prototypes shared by its translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "amc_device.h"
+
+// ---- SoA particle state in HBM (one allocation each, float64[n]; flag uint8[n]) --------------------------------
+struct amc_state {
+    double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
+    double *px, *py, *pz;     // prior_{x,y,z}_vals — written only when keep_prior is set
+    uint8_t *flag;
+};
+
+// ---- detection grid: uniform cells of edge h >= collision_range, stored per z-layer inside a square xy window ---
+// (the pore's body is 68 nm wide inside a 300 nm bounding box: a dense grid would be ~12x larger than needed)
+struct amc_grid {
+    double x0, y0, z0, h;
+    int gx, gy, gz;           // global extent in cells
+    int ncells;               // stored cells = sum over layers of lay_n^2  (0 = no grid: all-pairs mode)
+    const int *lay_lo;        // [gz] first stored cell coordinate of the window (same for x and y)
+    const int *lay_n;         // [gz] window edge in cells
+    const int *lay_off;       // [gz] linear offset of the layer's first cell
+};
+
+struct amc_sorted {
+    double *sx, *sy, *sz;     // positions in cell order (x fastest, then y, then z layer)
+    int *sidx;                // particle index of each sorted entry
+    int *cell_start;          // [ncells+1] exclusive prefix of the per-cell counts
+    int *cell_count;          // [ncells]
+    int *cid, *rank;          // [n] cell id and arrival rank of each particle
+};
+
+// ---- resolve scratch ---------------------------------------------------------------------------------------------
+struct amc_resolve_ws {
+    int *cand_i, *cand_j;     // candidate pairs, i > j (particle indices)
+    int max_cand;
+    int *slot_of;             // [n] particle -> slot or -1
+    int max_slots;
+    int *sl_p, *sl_label, *sl_tmp;                 // [max_slots]
+    unsigned long long *sl_key;                    // sort keys (label<<32 | particle)
+    int *order;                                    // slots sorted by (label, particle)
+    double *sl_x, *sl_y, *sl_z, *sl_vx, *sl_vy, *sl_vz, *sl_d, *sl_dx, *sl_dy, *sl_dz;
+    uint8_t *sl_flag, *sl_moved;
+    int *edge_a, *edge_b;     // extra merge edges (slots) found by verification
+    int max_edges;
+    int *hist_slot;           // position history of the current round: slot and new position
+    double *hist_x, *hist_y, *hist_z;
+    int max_hist;
+    int *ov_head, *ov_next;   // overlay lists of history entries per grid cell ([ncells], [max_hist])
+    // events of the current round (completed paths, emitted at commit)
+    int *ev_phase, *ev_i, *ev_j, *ev_which;
+    long long *ev_cell;
+    double *ev_val;           // [max_events][4]
+    int max_events;
+    int *ctl;                 // small control block: counters & flags (see amc_resolve.hip)
+};
+
+struct amc_ctx {
+    amc_params P;
+    int device;
+    hipStream_t own_stream, stream;
+    std::string err;
+    int64_t n, lo, hi;
+    bool uploaded;
+    bool keep_prior;
+    amc_state S;
+    amc_grid G;
+    std::vector<int> h_lay_lo, h_lay_n, h_lay_off;
+    int *d_lay;               // device copy of the three layer tables, contiguous
+    amc_sorted B;
+    int *scan_tmp;
+    int scan_blocks;
+    amc_resolve_ws W;
+    bool allpairs;
+    // outputs
+    amc_out out;
+    amc_path_record *d_rec;
+    unsigned long long *d_hist;
+    double *d_edges;
+    amc_dev_counters *d_cnt;
+    amc_dev_counters h_prev;  // snapshot used to report per-step deltas
+    // profiling
+    bool profiling;
+    double k_ms[AMC_K_COUNT];
+    int64_t k_launches[AMC_K_COUNT];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<std::pair<int, int>> ev_pending;   // (kernel class, pool index)
+    size_t ev_used;
+    // multi-GPU exchange
+    void *xchg_send, *xchg_recv;
+    int64_t xchg_stride;
+};
+
+int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
+#define AMC_HIP(c, call)                                                                                      \
+    do {                                                                                                      \
+        hipError_t e__ = (call);                                                                              \
+        if (e__ != hipSuccess) return amc_fail((c), AMC_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
+                                               hipGetErrorString(e__), __FILE__, __LINE__);                   \
+    } while (0)
+
+// profiling brackets
+void amc_prof_begin(amc_ctx *c, int kclass);
+void amc_prof_end(amc_ctx *c);
+void amc_prof_collect(amc_ctx *c);
+
+// stage bits of the streaming kernel
+#define AMC_ST_DRIFT 1
+#define AMC_ST_WALLS 2
+#define AMC_ST_BOUNDS 4
+
+// launchers (each enqueues on c->stream; returns hipError_t of the launch)
+hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot);
+hipError_t amc_launch_bin(amc_ctx *c);                 // count + scan + scatter over all n particles
+hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
+hipError_t amc_launch_resolve(amc_ctx *c);

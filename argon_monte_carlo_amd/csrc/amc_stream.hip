@@ -1,0 +1,133 @@
+// amc_stream.hip — the per-particle streaming stage: drift + free-path accumulation + wall cases + bounds check,
+// fused into ONE pass over the SoA state (reference: Cube:179-226, Pore:426-485 + 354-375/512).
+//
+// Roofline: HBM-bound.  Algorithmic traffic per particle-step: read pos 24 + vel 24 + 4 accumulators 32 + flag 1
+// = 81 B, write pos 24 + accumulators 32 = 56 B  => 137 B (velocity/flag writes happen only for the ~0.06 % of
+// particles that hit a wall).  One thread per particle, 256-thread blocks, fully coalesced 8-B lanes.
+//
+// Legality of the fusion: every wall case and every bounds test reads and writes only the particle itself, and
+// the reference evaluates the cases in a fixed order with each mask computed after the previous handler ran
+// (Pore:442-485) — which is exactly a per-particle sequential evaluation.
+#include "amc_internal.h"
+
+template <int GEOM>
+__global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
+                                                long long lo, long long hi, int keep_prior, int bounds_slot)
+{
+    const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hi) return;
+    amc_particle q;
+    q.x = S.x[p]; q.y = S.y[p]; q.z = S.z[p];
+    q.vx = S.vx[p]; q.vy = S.vy[p]; q.vz = S.vz[p];
+    const double x_in = q.x, y_in = q.y, z_in = q.z, vx_in = q.vx, vy_in = q.vy, vz_in = q.vz;
+    const bool need_acc = (stages & (AMC_ST_DRIFT | AMC_ST_WALLS)) != 0;
+    bool flag_in = false;
+    double d_in = 0, dx_in = 0, dy_in = 0, dz_in = 0;
+    if (need_acc) {
+        q.d = S.d[p]; q.dx = S.dx[p]; q.dy = S.dy[p]; q.dz = S.dz[p];
+        q.flag = S.flag[p] != 0;
+        flag_in = q.flag; d_in = q.d; dx_in = q.dx; dy_in = q.dy; dz_in = q.dz;
+    }
+    double px = q.x, py = q.y, pz = q.z;          // prior_*_vals (Pore:427-429)
+
+    if (stages & AMC_ST_DRIFT) {                  // Pore:430-437 / Cube:180-187 (ndarray ops: exact products)
+        const double sx = dt * q.vx, sy = dt * q.vy, sz = dt * q.vz;
+        q.x += sx; q.y += sy; q.z += sz;
+        q.d += fabs(sqrt(sx * sx + sy * sy + sz * sz));
+        q.dx += fabs(sx); q.dy += fabs(sy); q.dz += fabs(sz);
+        if (keep_prior && GEOM != AMC_GEOM_CUBE) { S.px[p] = px; S.py[p] = py; S.pz[p] = pz; }
+    } else if (GEOM != AMC_GEOM_CUBE && (stages & AMC_ST_WALLS)) {
+        px = S.px[p]; py = S.py[p]; pz = S.pz[p];
+    }
+
+    int nwall = 0, nerr = 0;
+    if (stages & AMC_ST_WALLS) {
+        if (GEOM == AMC_GEOM_CUBE) {              // Cube:189-226: per axis, max wall then min wall
+#define AMC_CUBE_AXIS(pos, vel, W)                                                                    \
+    if (pos > W) { const double t_ = (pos - W) / vel; vel = -vel; pos = W + t_ * vel; }                \
+    if (pos < 0) { const double t_ = pos / vel; vel = -vel; pos = t_ * vel; }
+            AMC_CUBE_AXIS(q.x, q.vx, P.cube_x)
+            AMC_CUBE_AXIS(q.y, q.vy, P.cube_y)
+            AMC_CUBE_AXIS(q.z, q.vz, P.cube_z)
+#undef AMC_CUBE_AXIS
+        } else if (GEOM == AMC_GEOM_PORE) {       // Pore:439-485, cases in order
+            const int ip = (int)p;
+            const double zb = P.z_gap_bottom, zt = P.z_gap_top;
+            const double r0 = sqrt(px * px + py * py);
+            if (sqrt(q.x * q.x + q.y * q.y) > P.R_oa) {                                  // CASE 1, Pore:442
+                if (amc_side_wall(q, P.R_oa_c, true, O, 1, ip)) nerr++; else nwall++;
+            }
+            if (q.z < 0) { amc_vertical_wall(q, 0.0, O, 2, ip); nwall++; }              // CASE 2, Pore:448
+            if (q.z > P.H) { amc_vertical_wall(q, P.H, O, 3, ip); nwall++; }            // Pore:451
+            if ((pz > P.z_cold) && (q.z < P.z_cold) && (sqrt(q.x * q.x + q.y * q.y) > P.R_p)) {   // CASE 3 cold, Pore:457
+                amc_vertical_wall(q, P.z_cold, O, 4, ip); nwall++;
+            }
+            if ((pz < P.h_oa) && (q.z > P.h_oa) && (sqrt(q.x * q.x + q.y * q.y) > P.R_p)) {       // CASE 3 hot, Pore:460
+                amc_vertical_wall(q, P.h_oa, O, 5, ip); nwall++;
+            }
+            if ((pz < zt) && (pz > zb) && (r0 < P.R_g) && (sqrt(q.x * q.x + q.y * q.y) > P.R_g)) { // CASE 4, Pore:465
+                if (amc_side_wall(q, P.R_g_c, true, O, 6, ip)) nerr++; else nwall++;
+            }
+            if ((r0 > P.R_p) && (q.z < zb) && (pz < zt) && (pz > zb)) {                 // CASE 5 bottom, Pore:472
+                amc_vertical_wall(q, zb, O, 7, ip); nwall++;
+            }
+            if ((r0 > P.R_p) && (q.z > zt) && (pz < zt) && (pz > zb)) {                 // CASE 5 top, Pore:476
+                amc_vertical_wall(q, zt, O, 8, ip); nwall++;
+            }
+            if ((r0 < P.R_p) && (sqrt(q.x * q.x + q.y * q.y) > P.R_p) &&
+                (((q.z < P.z_cold) && (q.z > zt)) || ((q.z < zb) && (q.z > P.h_oa)))) { // CASE 6, Pore:482
+                if (amc_side_wall(q, P.R_p_c, true, O, 9, ip)) nerr++; else nwall++;
+            }
+        }
+    }
+
+    int noob = 0;
+    if ((stages & AMC_ST_BOUNDS) && GEOM != AMC_GEOM_CUBE)
+        noob = amc_bounds(P, q.x, q.y, q.z, GEOM == AMC_GEOM_PORE_ENERGISED);        // Pore:512 / Temp:804
+
+    // write back only what changed (positions and accumulators always change in a drift step)
+    if (q.x != x_in) S.x[p] = q.x;
+    if (q.y != y_in) S.y[p] = q.y;
+    if (q.z != z_in) S.z[p] = q.z;
+    if (q.vx != vx_in) S.vx[p] = q.vx;
+    if (q.vy != vy_in) S.vy[p] = q.vy;
+    if (q.vz != vz_in) S.vz[p] = q.vz;
+    if (need_acc) {
+        if (q.d != d_in) S.d[p] = q.d;
+        if (q.dx != dx_in) S.dx[p] = q.dx;
+        if (q.dy != dy_in) S.dy[p] = q.dy;
+        if (q.dz != dz_in) S.dz[p] = q.dz;
+        if (q.flag != flag_in) S.flag[p] = 1;
+    }
+    if (nwall) atomicAdd(&O.cnt->n_wall, (unsigned long long)nwall);
+    if (nerr) atomicAdd(&O.cnt->n_fp_errors, (unsigned long long)nerr);
+    if (noob) atomicAdd(bounds_slot ? &O.cnt->n_oob_pp : &O.cnt->n_oob_walls, (unsigned long long)noob);
+}
+
+hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot)
+{
+    const long long cnt = c->hi - c->lo;
+    if (cnt <= 0) return hipSuccess;
+    const int threads = 256;
+    const unsigned blocks = (unsigned)((cnt + threads - 1) / threads);
+    const int kp = c->keep_prior ? 1 : 0;
+    amc_prof_begin(c, (stages == AMC_ST_BOUNDS) ? AMC_K_BOUNDS : AMC_K_DRIFT_WALLS);
+    switch (c->P.geometry) {
+    case AMC_GEOM_CUBE:
+        hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
+                           stages, c->lo, c->hi, kp, bounds_slot);
+        break;
+    case AMC_GEOM_PORE:
+        hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
+                           stages, c->lo, c->hi, kp, bounds_slot);
+        break;
+    case AMC_GEOM_PORE_ENERGISED:
+        hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
+                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot);
+        break;
+    default:
+        break;
+    }
+    amc_prof_end(c);
+    return hipGetLastError();
+}

@@ -1,0 +1,158 @@
+"""Thin object wrapper over the C ABI: one ``Engine`` = one ``amc_ctx`` = the particle state resident in HBM."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._abi import (AMC_K_NAMES, AmcParams, AmcPathRecord, AmcStepStats, path_record_dtype)
+
+_dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a, n):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != (n,):
+        raise ValueError(f"expected float64[{n}], got {a.shape}")
+    return a
+
+
+class Engine:
+    def __init__(self, params: AmcParams):
+        self.lib = _lib.load()
+        self.params = params
+        self.n = int(params.n)
+        self._ctx = C.c_void_p()
+        rc = self.lib.amc_create(C.byref(self._ctx), C.byref(params))
+        if rc != 0:
+            msg = self.lib.amc_last_error(None)
+            raise _lib.ArgonMCError(rc, msg.decode() if msg else "amc_create failed")
+
+    def _ck(self, rc):
+        if rc != 0:
+            msg = self.lib.amc_last_error(self._ctx)
+            raise _lib.ArgonMCError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self._ctx:
+            self.lib.amc_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state -----------------------------------------------------------------------------------------------
+    def upload(self, x=None, y=None, z=None, vx=None, vy=None, vz=None, d=None, dx=None, dy=None, dz=None, flag=None):
+        arrs = [_f64(a, self.n) for a in (x, y, z, vx, vy, vz, d, dx, dy, dz)]
+        f = None
+        if flag is not None:
+            f = np.ascontiguousarray(np.asarray(flag).astype(np.uint8))
+        self._ck(self.lib.amc_upload(self._ctx, *[_d(a) for a in arrs],
+                                     None if f is None else f.ctypes.data_as(C.POINTER(C.c_uint8))))
+
+    def download(self):
+        n = self.n
+        arrs = [np.empty(n) for _ in range(10)]
+        f = np.empty(n, dtype=np.uint8)
+        self._ck(self.lib.amc_download(self._ctx, *[_d(a) for a in arrs], f.ctypes.data_as(C.POINTER(C.c_uint8))))
+        keys = ["x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz"]
+        out = dict(zip(keys, arrs))
+        out["flag"] = f
+        return out
+
+    def download_prior(self):
+        a = [np.empty(self.n) for _ in range(3)]
+        self._ck(self.lib.amc_download_prior(self._ctx, *[_d(v) for v in a]))
+        return a
+
+    # -- stepping ----------------------------------------------------------------------------------------------
+    def timestep(self, dt):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_timestep(self._ctx, float(dt), C.byref(st)))
+        return st.as_dict()
+
+    def run(self, dt, nsteps):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_run(self._ctx, float(dt), int(nsteps), C.byref(st)))
+        return st.as_dict()
+
+    def stage_drift(self, dt):
+        self._ck(self.lib.amc_stage_drift(self._ctx, float(dt)))
+
+    def stage_walls(self):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_stage_walls(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def stage_bounds(self):
+        n = C.c_int64(0)
+        self._ck(self.lib.amc_stage_bounds(self._ctx, C.byref(n)))
+        return n.value
+
+    def stage_sweep(self):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_stage_sweep(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def pairwise_cell(self, cont, cx, cy, cz, flag, x, y, z, vx, vy, vz):
+        """One cell through the device pair kernel; arrays are updated IN PLACE (float64 / uint8, contiguous)."""
+        n = len(x)
+        cap = max(16, 8 * n)
+        paths = np.zeros((4, cap))
+        npaths = C.c_size_t(0)
+        ncoll = C.c_int64(0)
+        self._ck(self.lib.amc_pairwise_cell(self._ctx, n, _d(cont), _d(cx), _d(cy), _d(cz),
+                                            flag.ctypes.data_as(C.POINTER(C.c_uint8)), _d(x), _d(y), _d(z), _d(vx),
+                                            _d(vy), _d(vz), _d(paths), cap, C.byref(npaths), C.byref(ncoll)))
+        return paths[:, :npaths.value].T.copy(), ncoll.value
+
+    # -- outputs -------------------------------------------------------------------------------------------------
+    def drain_paths(self, sort=True):
+        pend = C.c_size_t(0)
+        self._ck(self.lib.amc_paths_pending(self._ctx, C.byref(pend)))
+        rec = np.zeros(max(1, pend.value), dtype=path_record_dtype())
+        got = C.c_size_t(0)
+        self._ck(self.lib.amc_drain_paths(self._ctx, rec.ctypes.data_as(C.POINTER(AmcPathRecord)), len(rec),
+                                          C.byref(got)))
+        rec = rec[:got.value]
+        if sort and len(rec):
+            # the reference's append order: step, wall cases in evaluation order, then colour groups / cells,
+            # inside a cell i ascending, j ascending, particle j before particle i (Pore:168-199)
+            rec = rec[np.lexsort((rec["which"], rec["j"], rec["i"], rec["cell"], rec["phase"], rec["step"]))]
+        return rec
+
+    def histograms(self):
+        nb = int(self.params.hist_bins)
+        counts = np.zeros((4, nb), dtype=np.uint64)
+        tot = C.c_uint64(0)
+        self._ck(self.lib.amc_histograms(self._ctx, counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(tot)))
+        return counts, tot.value
+
+    def reset_outputs(self):
+        self._ck(self.lib.amc_reset_outputs(self._ctx))
+
+    # -- measurement -----------------------------------------------------------------------------------------------
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.amc_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._ck(self.lib.amc_synchronize(self._ctx))
+
+    def profile(self, on=True):
+        self._ck(self.lib.amc_profile(self._ctx, int(on)))
+
+    def kernel_times(self):
+        ms = np.zeros(8)
+        cnt = np.zeros(8, dtype=np.int64)
+        self._ck(self.lib.amc_kernel_times(self._ctx, _d(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+        return {AMC_K_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(8)}

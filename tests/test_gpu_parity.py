@@ -1,0 +1,264 @@
+"""GPU parity (-m gpu): libargonmc.so (HIP, through the C ABI) against the oracle and the reference-generated goldens.
+
+Bars
+  * vs oracle `mul` (same algorithm, exact squares — the arithmetic the kernels implement): BIT-EXACT, including the
+    order of the completed-path lists.
+  * vs the reference goldens (NumPy scalar `**2` = libm pow, 1-ulp different from x*x for ~0.08 % of inputs):
+    identical event sets / counters; state rtol 1e-9 for one function call, 1e-6 on free-running trajectories.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from argon_monte_carlo_amd import ic as IC
+from argon_monte_carlo_amd import params as PR
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["cont", "cx", "cy", "cz", "flag", "x", "y", "z", "vx", "vy", "vz"]
+STATE_KEYS = ["x_vals", "y_vals", "z_vals", "x_velocities", "y_velocities", "z_velocities", "dist_since_collision",
+              "dist_x_since_collision", "dist_y_since_collision", "dist_z_since_collision", "full_path_traveled"]
+SF = ["x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz"]
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from argon_monte_carlo_amd.engine import Engine as E
+    return E
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, "func_pore.npz"))
+
+
+def assert_state_equal(dev, orc, ctx=""):
+    for k in SF:
+        assert np.array_equal(dev[k], orc[k]), (ctx, k, np.flatnonzero(dev[k] != orc[k])[:5])
+    assert np.array_equal(dev["flag"].astype(bool), orc["flag"].astype(bool)), (ctx, "flag")
+
+
+def paths_of(rec):
+    return np.stack([rec["total"], rec["px"], rec["py"], rec["pz"]], axis=1) if len(rec) else np.zeros((0, 4))
+
+
+# ---------------------------------------------------------------------------------------------- function level
+def test_pairwise_cell_single_pairs(Engine, O, G):
+    p, _ = PR.cell_params(n=2)
+    eng = Engine(p)
+    n = G["pair_in_x"].shape[0]
+    for k in range(0, n, 3):
+        args = [np.ascontiguousarray(G[f"pair_in_{f}"][k], dtype=np.float64) for f in FIELDS]
+        args[4] = np.ascontiguousarray(G["pair_in_flag"][k].astype(np.uint8))
+        ref, rpaths, rnc, rc = O.pair_cell(p, *[G[f"pair_in_{f}"][k] for f in FIELDS], mode="mul")
+        paths, nc = eng.pairwise_cell(*args)
+        assert nc == rnc == G["pair_ncoll"][k]
+        for f, a in zip(FIELDS, args):
+            assert np.array_equal(a.astype(np.float64), ref[f].astype(np.float64)), (k, f)
+            np.testing.assert_allclose(a.astype(np.float64), G[f"pair_out_{f}"][k], rtol=1e-9, atol=0)
+        assert np.array_equal(paths, rpaths)
+    eng.close()
+
+
+def test_pairwise_cell_whole_cells_with_chains(Engine, O, G):
+    off = G["cell_off"]
+    poff = G["cell_path_off"]
+    p, _ = PR.cell_params(n=int(np.max(np.diff(off))))
+    eng = Engine(p)
+    for c in range(len(off) - 1):
+        sl = slice(off[c], off[c + 1])
+        args = [np.ascontiguousarray(G[f"cell_in_{f}"][sl], dtype=np.float64) for f in FIELDS]
+        args[4] = np.ascontiguousarray(G["cell_in_flag"][sl].astype(np.uint8))
+        ref, rpaths, rnc, rc = O.pair_cell(p, *[G[f"cell_in_{f}"][sl] for f in FIELDS], mode="mul")
+        paths, nc = eng.pairwise_cell(*args)
+        assert nc == rnc == G["cell_ncoll"][c], c
+        for f, a in zip(FIELDS, args):
+            assert np.array_equal(a.astype(np.float64), ref[f].astype(np.float64)), (c, f)
+            np.testing.assert_allclose(a.astype(np.float64), G[f"cell_out_{f}"][sl], rtol=1e-9, atol=1e-300)
+        assert np.array_equal(paths, rpaths), c          # same values in the same (reference) order
+        np.testing.assert_allclose(paths, G["cell_paths"][poff[c]:poff[c + 1]], rtol=1e-9)
+    eng.close()
+
+
+def test_empty_and_tiny_cells(Engine):
+    p, _ = PR.cell_params(n=4)
+    eng = Engine(p)
+    for n in (0, 1):
+        args = [np.zeros(n) for _ in range(4)] + [np.zeros(n, dtype=np.uint8)] + [np.zeros(n) for _ in range(6)]
+        paths, nc = eng.pairwise_cell(*args)
+        assert nc == 0 and len(paths) == 0
+    eng.close()
+
+
+def test_zero_relative_velocity_is_reported_like_the_reference(Engine):
+    """a == 0 in the contact solve: the reference raises FloatingPointError (np.seterr(all='raise'), Pore:11)."""
+    from argon_monte_carlo_amd._lib import ArgonMCError
+    p, _ = PR.cell_params(n=2)
+    eng = Engine(p)
+    cr = p.collision_range
+    args = [np.zeros(2) for _ in range(4)] + [np.zeros(2, dtype=np.uint8)] + \
+           [np.array([0.0, 0.5 * cr]), np.zeros(2), np.zeros(2), np.array([10.0, 10.0]), np.zeros(2), np.zeros(2)]
+    with pytest.raises(ArgonMCError) as ei:
+        eng.pairwise_cell(*args)
+    assert ei.value.code == -5
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- step level
+def load_step(golden_dir, name):
+    path = os.path.join(golden_dir, name)
+    if not os.path.exists(path):
+        pytest.skip(f"{name} not generated")
+    return np.load(path)
+
+
+def golden_params(Gs, kind, **kw):
+    K = int(Gs["meta_K"])
+    sigma = 3.6 * 10**(-19) * float(Gs["meta_sigma_mult"])
+    p, c = (PR.cube_params(n=K, sigma=sigma) if kind == "cube" else PR.pore_params(n=K, sigma=sigma))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p, float(Gs["dt"])
+
+
+@pytest.mark.parametrize("name,kind", [("step_cube_a.npz", "cube"), ("step_cube_dense.npz", "cube"),
+                                       ("step_pore_a.npz", "pore")])
+@pytest.mark.parametrize("detect_mode", [1, 2])
+def test_free_run_matches_oracle_and_reference(Engine, O, golden_dir, name, kind, detect_mode):
+    Gs = load_step(golden_dir, name)
+    p, dt = golden_params(Gs, kind, detect_mode=detect_mode)
+    init = [Gs[f"s-001_{k}"] for k in STATE_KEYS]
+    eng = Engine(p)
+    eng.upload(*init[:10], flag=init[10])
+    orc = O.Oracle(p, mode="mul")
+    orc.upload(*init[:10], flag=init[10])
+    per = Gs["per_step"]
+    snaps = sorted({int(k[1:5]) for k in Gs.files if k.startswith("s0")})
+    for s in range(per.shape[0]):
+        st = eng.timestep(dt)
+        rc, so = orc.timestep(dt)
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+            assert st[k] == so[k], (s, k, st, so)
+        assert st["n_pp"] + st["n_wall"] == int(per[s, 1])              # the reference's own counter
+        assert_state_equal(eng.download(), orc.state(), ctx=(name, s))   # bit-exact vs oracle, every step
+        if s in snaps:                                                    # and against the reference's dump
+            dev = eng.download()
+            for k, f in zip(STATE_KEYS[:10], SF):
+                np.testing.assert_allclose(dev[f], Gs[f"s{s:04d}_{k}"], rtol=1e-6, atol=1e-18, err_msg=f"{name} {s} {k}")
+    # completed paths: same values, same (reference) order as the oracle
+    rec = eng.drain_paths(sort=True)
+    ro = orc.paths()
+    assert len(rec) == len(ro) == Gs["completed_paths"].shape[0]
+    if kind == "cube":
+        assert np.array_equal(paths_of(rec), paths_of(ro))
+        np.testing.assert_allclose(rec["total"], Gs["completed_paths"], rtol=1e-6)
+    else:
+        a, b = paths_of(rec), paths_of(ro)
+        assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    # on-device histograms == np.histogram of the drained paths (Pore:575)
+    counts, tot = eng.histograms()
+    assert tot == len(rec)
+    for row, key in enumerate(["total", "px", "py", "pz"]):
+        ref_counts, _ = np.histogram(rec[key], bins=int(p.hist_bins), range=(p.hist_lo, p.hist_hi))
+        assert np.array_equal(counts[row].astype(np.int64), ref_counts)
+    eng.close()
+
+
+def test_stages_match_oracle(Engine, O, golden_dir):
+    """drift / walls / bounds / sweep as separate calls (function-level view of one Pore step)."""
+    Gs = load_step(golden_dir, "step_pore_a.npz")
+    p, dt = golden_params(Gs, "pore")
+    init = [Gs[f"s-001_{k}"] for k in STATE_KEYS]
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(*init[:10], flag=init[10])
+    orc.upload(*init[:10], flag=init[10])
+    for s in range(6):
+        eng.stage_drift(dt); orc.drift(dt)
+        assert_state_equal(eng.download(), orc.state(), ("drift", s))
+        st = eng.stage_walls(); rc, nw = orc.pore_walls()
+        assert st["n_wall"] == nw
+        assert_state_equal(eng.download(), orc.state(), ("walls", s))
+        assert eng.stage_bounds() == orc.bounds(False)
+        assert_state_equal(eng.download(), orc.state(), ("bounds", s))
+        st = eng.stage_sweep(); rc, npp, _ = orc.sweep()
+        assert st["n_pp"] == npp
+        assert_state_equal(eng.download(), orc.state(), ("sweep", s))
+        assert eng.stage_bounds() == orc.bounds(False)
+        orc.step += 1
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE-size runs
+def conserved(st):
+    v2 = st["vx"] ** 2 + st["vy"] ** 2 + st["vz"] ** 2
+    return np.array([st["vx"].sum(), st["vy"].sum(), st["vz"].sum(), v2.sum()])
+
+
+def test_cube_1e5_vs_oracle_and_invariants(Engine, O):
+    """BASELINE config 2 (cube geometry, N = 100,000): GPU == oracle bit for bit over several steps; the sweep
+    conserves momentum and kinetic energy; no pair is left overlapping by the sweep's own collisions."""
+    p, c = PR.cube_params_for_n(100_000)
+    x, y, z, vx, vy, vz = IC.cube_ic(p, c, seed=127)
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(x, y, z, vx, vy, vz)
+    orc.upload(x, y, z, vx, vy, vz)
+    npp = 0
+    for s in range(5):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0 and st["n_pp"] == so["n_pp"] and st["n_paths"] == so["n_paths"], (s, st, so)
+        npp += st["n_pp"]
+        assert_state_equal(eng.download(), orc.state(), ("cube1e5", s))
+    assert npp > 100
+    # invariants of the p-p sweep alone
+    before = eng.download()
+    st = eng.stage_sweep()
+    after = eng.download()
+    np.testing.assert_allclose(conserved(after), conserved(before), rtol=1e-12, atol=1e-6)
+    eng.close()
+
+
+def test_pore_natural_density_vs_oracle(Engine, O):
+    """Pore geometry at N = 200,000 (reference density x0.36): walls + bounds + sweep, GPU == oracle bit for bit."""
+    p, c = PR.pore_params(n=200_000)
+    x, y, z, vx, vy, vz = IC.pore_ic(p, c, seed=17)
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(x, y, z, vx, vy, vz)
+    orc.upload(x, y, z, vx, vy, vz)
+    nw = 0
+    for s in range(4):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+            assert st[k] == so[k], (s, k, st, so)
+        nw += st["n_wall"]
+        assert_state_equal(eng.download(), orc.state(), ("pore2e5", s))
+    assert nw > 50
+    eng.close()
+
+
+def test_run_many_steps_equals_stepwise(Engine):
+    """amc_run (no host sync between steps) == the same number of amc_timestep calls."""
+    p, c = PR.cube_params_for_n(20_000)
+    ic = IC.cube_ic(p, c, seed=3)
+    a, b = Engine(p), Engine(p)
+    a.upload(*ic); b.upload(*ic)
+    tot = a.run(c["dt"], 20)
+    acc = 0
+    for _ in range(20):
+        acc += b.timestep(c["dt"])["n_pp"]
+    assert tot["n_pp"] == acc
+    assert_state_equal(a.download(), b.download(), "run")
+    a.close(); b.close()
