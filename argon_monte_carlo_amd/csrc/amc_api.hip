@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -95,9 +96,10 @@ static int setup_grid(amc_ctx *c)
     double h = P.fine_cell;
     if (!(h > 0)) {
         const double spacing = cbrt(volume / (double)std::max<int64_t>(1, c->n));
-        h = std::max(spacing, 1.25 * cr);
+        h = std::max(spacing, 2.01 * cr);
     }
-    if (h < 1.0000001 * cr) return amc_fail(c, AMC_ERR_INVALID, "fine_cell %g must exceed collision_range %g", h, cr);
+    // probes look at the cells overlapped by a +-collision_range box: at most 2 per axis needs h >= 2*collision_range
+    if (h < 2.00001 * cr) return amc_fail(c, AMC_ERR_INVALID, "fine_cell %g must be at least 2x collision_range %g", h, cr);
     // keep the table bounded
     for (;;) {
         const double nxy = ceil((xhi - xlo) / h) + 2, nz = ceil((zhi - zlo) / h) + 2;
@@ -161,7 +163,9 @@ void amc_destroy(amc_ctx *c)
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
                     c->W.edge_b, c->W.hist_slot, c->W.hist_x, c->W.hist_y, c->W.hist_z, c->W.ov_head, c->W.ov_next,
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv};
+                    c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
+                    c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
+                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -201,6 +205,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
+    c->d_dbg = nullptr;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
     c->stream = nullptr;
     int rc = AMC_OK;
@@ -249,6 +254,10 @@ int amc_create(amc_ctx **out, const amc_params *p)
         W.max_hist = 8 * W.max_slots + 1024;
         W.max_events = 8 * W.max_slots + 1024;
         CK(dalloc(&W.cand_i, (size_t)W.max_cand)); CK(dalloc(&W.cand_j, (size_t)W.max_cand));
+        CK(dalloc(&W.cand_si, (size_t)W.max_cand)); CK(dalloc(&W.cand_sj, (size_t)W.max_cand));
+        CK(dalloc(&W.cst, (size_t)22 * W.max_cand));
+        CK(dalloc(&W.ctl, 64));
+        CK(hipMemsetAsync(W.ctl, 0, sizeof(int) * 64, c->stream));
         CK(dalloc(&W.slot_of, n));
         CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));
         const size_t ms = (size_t)W.max_slots;
@@ -257,6 +266,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
         for (auto pp : sl) CK(dalloc(pp, ms));
         CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms));
+        for (int k = 0; k < 10; k++) CK(dalloc(&W.cw_d[k], ms));
+        CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
         CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
         CK(dalloc(&W.hist_slot, (size_t)W.max_hist)); CK(dalloc(&W.hist_x, (size_t)W.max_hist));
         CK(dalloc(&W.hist_y, (size_t)W.max_hist)); CK(dalloc(&W.hist_z, (size_t)W.max_hist));
@@ -284,6 +295,10 @@ int amc_create(amc_ctx **out, const amc_params *p)
             ed[nb] = p->hist_hi;
             CK(hipMemcpy(c->d_edges, ed.data(), sizeof(double) * (nb + 1), hipMemcpyHostToDevice));
             c->out.nbins = nb; c->out.hist = c->d_hist; c->out.edges = c->d_edges;
+        }
+        if (getenv("AMC_DEBUG_RESOLVE")) {
+            CK(dalloc(&c->d_dbg, 16));
+            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 16, c->stream));
         }
         CK(hipStreamSynchronize(c->stream));
     }
@@ -399,7 +414,7 @@ static int finish_stats(amc_ctx *c, amc_step_stats *out)
         c->h_prev.flags = 0;
         return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 2 path records, 4 resolve)", f);
     }
-    if (st.n_fp_errors > 0 && c->P.geometry != AMC_GEOM_PORE_ENERGISED)
+    if (st.n_fp_errors > 0 && c->P.geometry != AMC_GEOM_PORE_ENERGISED && !(c->P.reserved1 & 1))
         return amc_fail(c, AMC_ERR_FP, "%lld event(s) where the reference raises FloatingPointError", (long long)st.n_fp_errors);
     return AMC_OK;
 }
@@ -615,6 +630,14 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
     if (!c) return AMC_ERR_INVALID;
     hipSetDevice(c->device);
     amc_prof_collect(c);
+    if (c->d_dbg) {
+        long long h[16];
+        hipMemcpy(h, c->d_dbg, sizeof h, hipMemcpyDeviceToHost);
+        const double n = h[11] > 0 ? (double)h[11] : 1.0;
+        fprintf(stderr, "[amc resolve phases, us/launch] claim %.1f label %.1f [collect %.1f tid0-pair %.1f (load %.1f ks %.1f collide+emit %.1f)] pairs-barrier %.1f complex %.1f validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
+                h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[13] / n / 100.0, h[14] / n / 100.0, h[12] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
+                h[8] / n, h[9] / n, h[10] / n, h[11]);
+    }
     for (int k = 0; k < AMC_K_COUNT; k++) {
         if (total_ms) total_ms[k] = c->k_ms[k];
         if (launches) launches[k] = c->k_launches[k];

@@ -80,13 +80,24 @@ struct amc_particle {
     bool flag;
 };
 
-AMC_DEV double amc_speed(double vx, double vy, double vz) { return sqrt(vx * vx + vy * vy + vz * vz); }
+// fp64 divide / sqrt are ~40-instruction expansions (correctly rounded).  The streaming kernel inlines them; the
+// resolve kernels (tens of KB of code executed once per launch by a handful of waves, i.e. instruction-fetch bound)
+// define AMC_COMPACT_MATH and call one shared copy instead.  Same arithmetic either way.
+#ifdef AMC_COMPACT_MATH
+static __device__ __noinline__ double amc_div(double a, double b) { return a / b; }
+static __device__ __noinline__ double amc_sqrt(double a) { return sqrt(a); }
+#else
+AMC_DEV double amc_div(double a, double b) { return a / b; }
+AMC_DEV double amc_sqrt(double a) { return sqrt(a); }
+#endif
+
+AMC_DEV double amc_speed(double vx, double vy, double vz) { return amc_sqrt(vx * vx + vy * vy + vz * vz); }
 
 // Pore:173-174 — the overlap test
 AMC_DEV bool amc_overlap(double x1, double y1, double z1, double x2, double y2, double z2, double cr)
 {
     double ex = x2 - x1, ey = y2 - y1, ez = z2 - z1;
-    return sqrt(ex * ex + ey * ey + ez * ez) < cr;
+    return amc_sqrt(ex * ex + ey * ey + ez * ez) < cr;
 }
 
 // Pore:176-241 — resolve one detected collision between p1 (= j, lower rank) and p2 (= i).
@@ -104,8 +115,8 @@ AMC_DEV int amc_collide(amc_particle &p1, amc_particle &p2, double cr, double m,
     const double c = ex * ex + ey * ey + ez * ez - cr * cr;                          // Pore:184
     const double disc2 = b * b - 4 * a * c;
     if (a == 0.0 || disc2 < 0.0 || a != a || disc2 != disc2) return 1;
-    const double sq = sqrt(disc2);
-    const double t1 = (-b + sq) / (2 * a), t2 = (-b - sq) / (2 * a);
+    const double sq = amc_sqrt(disc2);
+    const double t1 = amc_div(-b + sq, 2 * a), t2 = amc_div(-b - sq, 2 * a);
     const double t = (t1 > t2) ? t1 : t2;                                            // Pore:185
     if (p1.flag)                                                                     // Pore:186-190
         emit(0, fabs(p1.d - fabs(amc_speed(vx1, vy1, vz1) * t)), fabs(p1.dx - fabs(vx1 * t)),
@@ -119,10 +130,10 @@ AMC_DEV int amc_collide(amc_particle &p1, amc_particle &p2, double cr, double m,
         p2.flag = true;                                                              // Pore:199
     const double nx1 = x1 - vx1 * t, ny1 = y1 - vy1 * t, nz1 = z1 - vz1 * t;         // Pore:202
     const double nx2 = x2 - vx2 * t, ny2 = y2 - vy2 * t, nz2 = z2 - vz2 * t;
-    const double n0 = (nx2 - nx1) / cr, n1 = (ny2 - ny1) / cr, n2 = (nz2 - nz1) / cr;  // Pore:205-207
+    const double n0 = amc_div(nx2 - nx1, cr), n1 = amc_div(ny2 - ny1, cr), n2 = amc_div(nz2 - nz1, cr);  // Pore:205-207
     const double d1 = fma(vz1, n2, fma(vy1, n1, vx1 * n0));                          // Pore:209 (np.dot = FMA chain)
     const double d2 = fma(vz2, n2, fma(vy2, n1, vx2 * n0));
-    const double p = (d1 - d2) / m;
+    const double p = amc_div(d1 - d2, m);
     const double pm = p * m;
     const double wvx1 = vx1 - pm * n0, wvy1 = vy1 - pm * n1, wvz1 = vz1 - pm * n2;   // Pore:211-213
     const double wvx2 = vx2 + pm * n0, wvy2 = vy2 + pm * n1, wvz2 = vz2 + pm * n2;   // Pore:214-216
@@ -140,7 +151,7 @@ AMC_DEV int amc_collide(amc_particle &p1, amc_particle &p2, double cr, double m,
 // Pore:257-292 hit_vertical_wall for one particle.
 AMC_DEV void amc_vertical_wall(amc_particle &q, double z_plane, const amc_out &o, int phase, int idx)
 {
-    const double t = (q.z - z_plane) / q.vz;                                         // Pore:261
+    const double t = amc_div(q.z - z_plane, q.vz);                                   // Pore:261
     const double sp = amc_speed(q.vx, q.vy, q.vz);
     if (q.flag)                                                                      // Pore:274-278
         amc_emit(o, phase, 0, idx, -1, 0, fabs(q.d - fabs(sp * t)), fabs(q.dx - fabs(q.vx * t)),
@@ -163,11 +174,11 @@ AMC_DEV int amc_side_wall(amc_particle &q, double Rc, bool bookkeeping, const am
     const double c = x * x + y * y - Rc * Rc;                                        // Pore:314
     const double disc2 = b * b - 4 * a * c;
     if (a == 0.0 || disc2 < 0.0 || disc2 != disc2) return 1;
-    const double sq = sqrt(disc2);
-    const double t1 = (-b + sq) / (2 * a), t2 = (-b - sq) / (2 * a);
+    const double sq = amc_sqrt(disc2);
+    const double t1 = amc_div(-b + sq, 2 * a), t2 = amc_div(-b - sq, 2 * a);
     const double t = (t1 < t2) ? t1 : t2;                                            // Pore:315
     const double cx = x - vx * t, cy = y - vy * t;                                   // Pore:316
-    const double n0 = cx / Rc, n1 = cy / Rc;                                         // Pore:318
+    const double n0 = amc_div(cx, Rc), n1 = amc_div(cy, Rc);                         // Pore:318
     const double scalar = fma(vy, n1, vx * n0);                                      // Pore:320 (np.dot)
     const double s2 = 2 * scalar;
     const double wvx = vx - s2 * n0, wvy = vy - s2 * n1;                             // Pore:321

@@ -6,8 +6,7 @@
 // the reference's own cell membership and loop order.  Two detectors:
 //
 //   binned   : counting sort of the particles into cells of edge h ~ mean spacing (>= collision_range), x fastest,
-//              then a half-stencil search (own row forward + 4 neighbour rows, each a contiguous range of the sorted
-//              arrays).  O(N) work, HBM/L2-bound.  Algorithmic traffic 24 B/particle (positions read once);
+//              then each particle probes only the cells its collision_range box overlaps (1.7 on average).  O(N) work, HBM/L2-bound.  Algorithmic traffic 24 B/particle (positions read once);
 //              the sorted copy (28 B written + read) and the cell tables are implementation overhead.
 //   all-pairs: LDS-tiled j-block (256 particles = 6 KB) against 256 i-particles in registers, upper triangle of
 //              tiles only — the kernel the reference's pairwise_particles_in_cell maps to directly; fp64-VALU-bound
@@ -130,12 +129,28 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const double *__restrict__ 
 }
 
 // ---- binned detection: one thread per sorted particle, half stencil ------------------------------------------------
-AMC_DEV void amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
+// A candidate is stored as (i, j) with i > j plus a copy of both particles' state in a SoA table (cst[e][k], e = 0..10
+// particle j, 11..21 particle i): the single-workgroup resolve kernel then reads coalesced rows instead of issuing
+// 22 scattered loads per pair from one CU.
+AMC_DEV void amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
+                                const amc_state &S, double *cst)
 {
     const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
     if (k < (unsigned)max_cand) {
-        cand_i[k] = a > b ? a : b;
-        cand_j[k] = a > b ? b : a;
+        const int i = a > b ? a : b, j = a > b ? b : a;
+        cand_i[k] = i;
+        cand_j[k] = j;
+        const size_t m = (size_t)max_cand;
+        const int pp[2] = {j, i};
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const int p = pp[w];
+            double *t = cst + (size_t)(11 * w) * m + k;
+            t[0 * m] = S.x[p]; t[1 * m] = S.y[p]; t[2 * m] = S.z[p];
+            t[3 * m] = S.vx[p]; t[4 * m] = S.vy[p]; t[5 * m] = S.vz[p];
+            t[6 * m] = S.d[p]; t[7 * m] = S.dx[p]; t[8 * m] = S.dy[p]; t[9 * m] = S.dz[p];
+            t[10 * m] = S.flag[p] ? 1.0 : 0.0;
+        }
     } else {
         atomicOr(&cnt->flags, 1ULL);
     }
@@ -145,28 +160,24 @@ __global__ __launch_bounds__(256) void k_detect_binned(amc_grid G, const double 
                                                        const double *__restrict__ sy, const double *__restrict__ sz,
                                                        const int *__restrict__ sidx,
                                                        const int *__restrict__ cell_start, long long n, double cr2i,
-                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
+                                                       double cr_probe, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
+                                                       amc_state S, double *cst)
 {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const double x = sx[s], y = sy[s], z = sz[s];
     const int me = sidx[s];
-    int cx, cy, cz;
-    amc_grid_coords(G, x, y, z, cx, cy, cz);
-    // rows of the half stencil: (dy,dz) = (0,0) forward part, (1,0), (-1,1), (0,1), (1,1)
-    const int rdy[5] = {0, 1, -1, 0, 1};
-    const int rdz[5] = {0, 0, 1, 1, 1};
-#pragma unroll
-    for (int r = 0; r < 5; r++) {
-        int c_lo, c_hi;
-        if (!amc_grid_row(G, cx, cy + rdy[r], cz + rdz[r], c_lo, c_hi)) continue;
-        int q0 = cell_start[c_lo];
-        const int q1 = cell_start[c_hi + 1];
-        if (r == 0) q0 = (int)s + 1;       // own row: later entries of my cell and the next cell only
+    // cells overlapped by my collision_range box (1.7 on average, 8 at most); each pair is seen from both ends and
+    // emitted by the one that comes later in the sorted order
+    int cells[8];
+    const int nc = amc_grid_box_cells(G, x, y, z, cr_probe, cells);
+    for (int k = 0; k < nc; k++) {
+        const int q0 = cell_start[cells[k]], q1 = cell_start[cells[k] + 1];
         for (int q = q0; q < q1; q++) {
+            if (q <= (int)s) continue;
             const double ex = sx[q] - x, ey = sy[q] - y, ez = sz[q] - z;
             const double d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 < cr2i) amc_push_candidate(me, sidx[q], cand_i, cand_j, max_cand, cnt);
+            if (d2 < cr2i) amc_push_candidate(me, sidx[q], cand_i, cand_j, max_cand, cnt, S, cst);
         }
     }
 }
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(256) void k_detect_binned(amc_grid G, const double 
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ z, int n, int ntiles, double cr2i,
                                                           int *cand_i, int *cand_j, int max_cand,
-                                                          amc_dev_counters *cnt)
+                                                          amc_dev_counters *cnt, amc_state S, double *cst)
 {
     // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
     for (int k = 0; k < jmax; k++) {
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
         const double d2 = ex * ex + ey * ey + ez * ez;
-        if (d2 < cr2i) amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt);
+        if (d2 < cr2i) amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt, S, cst);
     }
 }
 
@@ -241,11 +252,11 @@ hipError_t amc_launch_detect(amc_ctx *c)
         const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
         if (nblocks > 0)
             hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
-                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt);
+                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst);
     } else {
         hipLaunchKernelGGL(k_detect_binned, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B.sx,
-                           c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, n, cr2i, c->W.cand_i, c->W.cand_j,
-                           c->W.max_cand, c->d_cnt);
+                           c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, n, cr2i, c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j,
+                           c->W.max_cand, c->d_cnt, c->S, c->W.cst);
     }
     amc_prof_end(c);
     return hipGetLastError();

@@ -43,3 +43,23 @@ AMC_DEV bool amc_grid_row(const amc_grid &G, int cx, int cy, int cz, int &c_lo, 
     c_hi = base + x_hi;
     return true;
 }
+
+// The stored cells that can hold a particle within distance r of (x,y,z): the cells overlapped by the box
+// [x-r,x+r] x [y-r,y+r] x [z-r,z+r] — at most 2 per axis because h >= r — after the same monotone clamps that
+// amc_grid_coords / amc_grid_cell apply to particles.  Writes up to 8 distinct cell ids, returns their number.
+AMC_DEV int amc_grid_box_cells(const amc_grid &G, double x, double y, double z, double r, int *cells)
+{
+    int x0, y0, z0, x1, y1, z1;
+    amc_grid_coords(G, x - r, y - r, z - r, x0, y0, z0);
+    amc_grid_coords(G, x + r, y + r, z + r, x1, y1, z1);
+    int n = 0;
+    for (int cz = z0; cz <= z1; cz++)
+        for (int cy = y0; cy <= y1; cy++)
+            for (int cx = x0; cx <= x1; cx++) {
+                const int c = amc_grid_cell(G, cx, cy, cz, nullptr);
+                bool dup = false;
+                for (int k = 0; k < n; k++) dup |= (cells[k] == c);
+                if (!dup && n < 8) cells[n++] = c;
+            }
+    return n;
+}

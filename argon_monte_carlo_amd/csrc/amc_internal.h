@@ -37,6 +37,7 @@ struct amc_sorted {
 // ---- resolve scratch ---------------------------------------------------------------------------------------------
 struct amc_resolve_ws {
     int *cand_i, *cand_j;     // candidate pairs, i > j (particle indices)
+    int *cand_si, *cand_sj;   // the same pairs as slot ids (filled by the resolve kernel)
     int max_cand;
     int *slot_of;             // [n] particle -> slot or -1
     int max_slots;
@@ -45,6 +46,9 @@ struct amc_resolve_ws {
     int *order;                                    // slots sorted by (label, particle)
     double *sl_x, *sl_y, *sl_z, *sl_vx, *sl_vy, *sl_vz, *sl_d, *sl_dx, *sl_dy, *sl_dz;
     uint8_t *sl_flag, *sl_moved;
+    double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
+    int *cw_tmp, *cw_pidx;
+    uint8_t *cw_flag, *cw_moved;
     int *edge_a, *edge_b;     // extra merge edges (slots) found by verification
     int max_edges;
     int *hist_slot;           // position history of the current round: slot and new position
@@ -56,7 +60,8 @@ struct amc_resolve_ws {
     long long *ev_cell;
     double *ev_val;           // [max_events][4]
     int max_events;
-    int *ctl;                 // small control block: counters & flags (see amc_resolve.hip)
+    int *ctl;                 // rs_shared in global memory: hand-over between the resolve kernels
+    double *cst;              // [22][max_cand] state of both particles of every candidate, gathered by detect
 };
 
 struct amc_ctx {
@@ -83,6 +88,7 @@ struct amc_ctx {
     double *d_edges;
     amc_dev_counters *d_cnt;
     amc_dev_counters h_prev;  // snapshot used to report per-step deltas
+    long long *d_dbg;         // resolve phase timers (diagnostic, enabled by AMC_DEBUG_RESOLVE=1)
     // profiling
     bool profiling;
     double k_ms[AMC_K_COUNT];
@@ -117,4 +123,4 @@ void amc_prof_collect(amc_ctx *c);
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot);
 hipError_t amc_launch_bin(amc_ctx *c);                 // count + scan + scatter over all n particles
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
-hipError_t amc_launch_resolve(amc_ctx *c);
+hipError_t amc_launch_resolve(amc_ctx *c);              // resolve_A -> validate -> resolve_B -> commit

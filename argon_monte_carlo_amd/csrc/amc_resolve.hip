@@ -7,24 +7,29 @@
 // so the work is organised as OPTIMISTIC CLUSTERS WITH CONSERVATIVE VALIDATION:
 //
 //   1. clusters = connected components of the candidate graph (label propagation, label = lowest particle index);
-//   2. one thread per cluster runs a LITERAL emulation of the reference restricted to the cluster's members —
-//      same colour-group / cell order, same membership predicates evaluated at the same moments (Pore:527-530;
-//      Cube's in_x/in_y/in_z masks are evaluated per x-layer / (x,y)-layer / cell, Cube:233-238), same i>j loop
-//      order (members sorted by particle index), same arithmetic (amc_collide) — on a scratch copy of the state;
-//   3. validation: every position a member occupied during the emulation is checked against all particles
-//      outside its cluster (pre-sweep positions via the detection grid, other clusters' new positions via an
-//      overlay list per grid cell).  Anything within collision_range*(1+1e-9) merges the clusters / pulls the
-//      particle in, and the round is repeated from the untouched pre-sweep state.  When a round validates, no
-//      test the reference performs between a member and a non-member can hit, hence the restricted emulation is
-//      exactly what the reference computes;
+//   2. every cluster gets a LITERAL emulation of the reference restricted to its members — same colour-group / cell
+//      order, same membership predicates evaluated at the same moments (Pore:527-530; Cube's in_x/in_y/in_z masks
+//      are evaluated per x-layer / (x,y)-layer / cell, Cube:233-238), same i>j loop order (members in ascending
+//      particle index), same arithmetic (amc_collide) — on a scratch copy of the state.
+//        * two-particle clusters (~99 %): one thread, both particles in registers, no sorting;
+//        * larger clusters: members sorted by (label, index) with a small bitonic sort, working set in LDS;
+//   3. validation: every position a member occupied during the emulation is checked against all particles outside
+//      its cluster (pre-sweep positions via the detection grid, other clusters' new positions via an overlay list
+//      per grid cell).  Anything within collision_range*(1+1e-9) merges the clusters / pulls the particle in, and
+//      the round is repeated from the untouched pre-sweep state.  When a round validates, no test the reference
+//      performs between a member and a non-member can hit, hence the restricted emulation is exactly what the
+//      reference computes;
 //   4. commit: scratch state -> particle arrays, completed paths -> histogram / record buffer, counters.
 //
-// The whole kernel is ONE 1024-thread workgroup (phases separated by __syncthreads, counters in LDS): the data set
-// is a few hundred pairs, so the cost is latency, not throughput.
+// The ordered logic runs in ONE 512-thread workgroup (phases separated by __syncthreads, counters in LDS): the data
+// set is a few hundred pairs, so the cost is latency, not throughput.  Everything that is scattered memory traffic
+// is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and the
+// first round's validation probes and the commit scatter are separate wide kernels.
 #include "amc_grid_dev.h"
 
-#define RS_T 1024
-#define RS_SORT_LDS 8192
+#define RS_T 512
+#define RS_SORT_LDS 2048       // complex-cluster members sorted in LDS up to this many
+#define RS_POOL 256            // complex-cluster working set held in LDS up to this many members
 #define RS_MAX_ROUNDS 256
 #define AMC_CR2_INFLATE (1.0 + 1.0e-9)
 
@@ -37,32 +42,57 @@ struct rs_args {
     amc_out O;
     long long n;
     int allpairs;
+    double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
+    long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
 };
 
-AMC_DEV amc_particle rs_load_slot(const amc_resolve_ws &W, int s)
+// counters of one sweep; lives in LDS while a resolve kernel runs and in W.ctl (global) between the kernels
+struct rs_shared {
+    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
+    int rounds, ncand, active, ok, edges_done;
+    int nslots0;              // slots that existed (and have labels in W.sl_label) when resolve_A handed over
+};
+
+// working set of the multi-particle clusters (LDS pool or global fallback), indexed by sorted rank
+struct rs_work {
+    double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
+    int *tmp, *pidx;
+    uint8_t *flag, *moved;
+};
+
+AMC_DEV amc_particle rs_load_particle(const amc_state &S, int p)
 {
     amc_particle q;
-    q.x = W.sl_x[s]; q.y = W.sl_y[s]; q.z = W.sl_z[s]; q.vx = W.sl_vx[s]; q.vy = W.sl_vy[s]; q.vz = W.sl_vz[s];
-    q.d = W.sl_d[s]; q.dx = W.sl_dx[s]; q.dy = W.sl_dy[s]; q.dz = W.sl_dz[s]; q.flag = W.sl_flag[s] != 0;
+    q.x = S.x[p]; q.y = S.y[p]; q.z = S.z[p]; q.vx = S.vx[p]; q.vy = S.vy[p]; q.vz = S.vz[p];
+    q.d = S.d[p]; q.dx = S.dx[p]; q.dy = S.dy[p]; q.dz = S.dz[p]; q.flag = S.flag[p] != 0;
     return q;
 }
 AMC_DEV void rs_store_slot(const amc_resolve_ws &W, int s, const amc_particle &q)
 {
     W.sl_x[s] = q.x; W.sl_y[s] = q.y; W.sl_z[s] = q.z; W.sl_vx[s] = q.vx; W.sl_vy[s] = q.vy; W.sl_vz[s] = q.vz;
     W.sl_d[s] = q.d; W.sl_dx[s] = q.dx; W.sl_dy[s] = q.dy; W.sl_dz[s] = q.dz; W.sl_flag[s] = q.flag ? 1 : 0;
+    W.sl_moved[s] = 1;
+}
+AMC_DEV amc_particle rs_load_work(const rs_work &K, int w)
+{
+    amc_particle q;
+    q.x = K.x[w]; q.y = K.y[w]; q.z = K.z[w]; q.vx = K.vx[w]; q.vy = K.vy[w]; q.vz = K.vz[w];
+    q.d = K.d[w]; q.dx = K.dx[w]; q.dy = K.dy[w]; q.dz = K.dz[w]; q.flag = K.flag[w] != 0;
+    return q;
+}
+AMC_DEV void rs_store_work(const rs_work &K, int w, const amc_particle &q)
+{
+    K.x[w] = q.x; K.y[w] = q.y; K.z[w] = q.z; K.vx[w] = q.vx; K.vy[w] = q.vy; K.vz[w] = q.vz;
+    K.d[w] = q.d; K.dx[w] = q.dx; K.dy[w] = q.dy; K.dz[w] = q.dz; K.flag[w] = q.flag ? 1 : 0;
+    K.moved[w] = 1;
 }
 
-struct rs_shared {
-    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters;
-};
-
-// one tested pair inside the emulation: exact overlap test on the scratch state, resolve on hit
-AMC_DEV void rs_test_pair(const rs_args &A, rs_shared *sh, int sj, int si, int phase, long long cell)
+// one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
+// Returns true if the particles moved.
+AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
+                    int si, int phase, long long cell)
 {
     const amc_resolve_ws &W = A.W;
-    if (!amc_overlap(W.sl_x[sj], W.sl_y[sj], W.sl_z[sj], W.sl_x[si], W.sl_y[si], W.sl_z[si], A.P.collision_range)) return;
-    amc_particle p1 = rs_load_slot(W, sj), p2 = rs_load_slot(W, si);
-    const int pi = W.sl_p[si], pj = W.sl_p[sj];
     auto emit = [&](int which, double tot, double px, double py, double pz) {
         const int e = atomicAdd(&sh->nev, 1);
         if (e < W.max_events) {
@@ -72,13 +102,13 @@ AMC_DEV void rs_test_pair(const rs_args &A, rs_shared *sh, int sj, int si, int p
             sh->ovf = 1;
         }
     };
-    if (amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit)) {
+    long long tq__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
+    const int fail__ = amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit);
+    if (A.dbg && threadIdx.x == 0) { if (p1.x == 1.2345e300) A.dbg[15] = 3; A.dbg[12] += wall_clock64() - tq__; }
+    if (fail__) {
         atomicAdd(&sh->nfp, 1);     // the reference would raise FloatingPointError here (Pore:11,185)
-        return;
+        return false;
     }
-    rs_store_slot(W, sj, p1);
-    rs_store_slot(W, si, p2);
-    W.sl_moved[sj] = 1; W.sl_moved[si] = 1;
     atomicAdd(&sh->nhits, 1);
     const int h = atomicAdd(&sh->nhist, 2);
     if (h + 1 < W.max_hist) {
@@ -87,27 +117,187 @@ AMC_DEV void rs_test_pair(const rs_args &A, rs_shared *sh, int sj, int si, int p
     } else {
         sh->ovf = 1;
     }
+    return true;
 }
 
-// literal emulation of the reference restricted to the members order[b..e) (sorted by particle index)
-AMC_DEV void rs_emulate(const rs_args &A, rs_shared *sh, int b, int e)
+AMC_DEV int rs_pore_cell(const amc_params &P, double x, double y, double z, int gx, int gy, int gz)
 {
-    const amc_resolve_ws &W = A.W;
+    const int lx = amc_axis_cell(x, gx, P.nx, P.nx, P.dx, P.overlap_x);
+    if (lx < 0) return -1;
+    const int ly = amc_axis_cell(y, gy, P.ny, P.ny, P.dy, P.overlap_y);
+    if (ly < 0) return -1;
+    const int lz = amc_axis_cell(z, gz, P.nz / 2, 0, P.dz, P.overlap_z);
+    if (lz < 0) return -1;
+    return (lx * P.ny + ly) * (P.nz / 2) + lz;                                              // Pore:530 list order
+}
+
+// The (at most two) integers k with  k*d - ov < v < (k+1)*d  (Pore:527-529 with k = 2*layer+group-offset): the core
+// cell of v and, if v lies in the overlap strip, the next one.  INT_MIN marks "none".
+AMC_DEV void rs_axis_k(double v, double d, double inv_d, double ov, int &ka, int &kb)
+{
+    ka = kb = (int)0x80000000;
+    const double f = floor(v * inv_d);
+    if (!(f > -1.0e9 && f < 1.0e9)) return;
+    for (int dk = -1; dk <= 1; dk++) {
+        const int k = (int)f + dk;
+        const double lo = (double)k * d - ov, hi = (double)(k + 1) * d;
+        if (lo < v && v < hi) { if (ka == (int)0x80000000) ka = k; else kb = k; }
+    }
+}
+AMC_DEV void rs_pore_ks(const rs_args &A, const amc_particle &q, int *k)
+{
     const amc_params &P = A.P;
-    const int *ord = W.order;
+    rs_axis_k(q.x, P.dx, A.inv_dx, P.overlap_x, k[0], k[1]);
+    rs_axis_k(q.y, P.dy, A.inv_dy, P.overlap_y, k[2], k[3]);
+    rs_axis_k(q.z, P.dz, A.inv_dz, P.overlap_z, k[4], k[5]);
+}
+// layer of colour group `grp` along one axis from the cached k's (same rule as amc_axis_cell), -1 if none
+AMC_DEV int rs_layer_from_k(int ka, int kb, int grp, int nlayers, int offset)
+{
+    for (int t = 0; t < 2; t++) {
+        const int k = t ? kb : ka;
+        if (k == (int)0x80000000) continue;
+        const int twol = k - grp + offset;
+        if (twol < 0 || (twol & 1)) continue;
+        const int l = twol / 2;
+        if (l < nlayers) return l;
+    }
+    return -1;
+}
+AMC_DEV int rs_pore_cell_k(const amc_params &P, const int *k, int g)
+{
+    const int lx = rs_layer_from_k(k[0], k[1], g >> 2, P.nx, P.nx);
+    if (lx < 0) return -1;
+    const int ly = rs_layer_from_k(k[2], k[3], (g >> 1) & 1, P.ny, P.ny);
+    if (ly < 0) return -1;
+    const int lz = rs_layer_from_k(k[4], k[5], g & 1, P.nz / 2, 0);
+    if (lz < 0) return -1;
+    return (lx * P.ny + ly) * (P.nz / 2) + lz;                                              // Pore:530 list order
+}
+
+// smallest layer l >= from with  l*d - ov < v < (l+1)*d  for BOTH v1 and v2 (Cube:233), or -1
+AMC_DEV int rs_next_common(double v1, double v2, double d, double inv_d, double ov, int n, int from)
+{
+    const double vmin = v1 < v2 ? v1 : v2, vmax = v1 < v2 ? v2 : v1;
+    // the layer of vmax's core interval is the only one that can also hold a smaller coordinate; one below / above
+    // are tested as well so that the floor() guess never decides membership (the comparisons do)
+    const double f = floor(vmax * inv_d);
+    if (!(f > -2.0 && f < 1.0e9)) return -1;
+    int l0 = (int)f - 1;
+    if (l0 < from) l0 = from;
+    int l1 = (int)f + 1;
+    if (l1 > n - 1) l1 = n - 1;
+    for (int l = l0; l <= l1; l++) {
+        const double lo = l * d - ov, hi = (l + 1) * d;
+        if ((lo < vmin) && (vmax < hi)) return l;
+    }
+    return -1;
+}
+
+// ---- two-particle cluster: literal emulation with both particles in registers -----------------------------------------
+AMC_DEV amc_particle rs_load_cst(const amc_resolve_ws &W, int k, int which)
+{
+    const size_t m = (size_t)W.max_cand;
+    const double *t = W.cst + (size_t)(11 * which) * m + k;
+    amc_particle q;
+    q.x = t[0 * m]; q.y = t[1 * m]; q.z = t[2 * m]; q.vx = t[3 * m]; q.vy = t[4 * m]; q.vz = t[5 * m];
+    q.d = t[6 * m]; q.dx = t[7 * m]; q.dy = t[8 * m]; q.dz = t[9 * m]; q.flag = t[10 * m] != 0.0;
+    return q;
+}
+
+template <int GEOM>
+AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int pi, int sj, int si)
+{
+    const amc_params &P = A.P;
+    long long t0__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
+    amc_particle p1 = rs_load_cst(A.W, k, 0), p2 = rs_load_cst(A.W, k, 1);   // coalesced rows gathered by detect
+    if (A.dbg && threadIdx.x == 0) { if (p1.x + p2.x == 1.2345e300) A.dbg[15] = 1; const long long t1__ = wall_clock64(); A.dbg[13] += t1__ - t0__; t0__ = t1__; }
+    bool moved = false;
+    const double cr = P.collision_range;
+    if (GEOM == AMC_GEOM_CELL) {
+        if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr)) moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, 0);
+    } else if (GEOM == AMC_GEOM_CUBE) {
+        // Cube:231-238.  A coordinate lies in at most two overlapping layers, so the layers holding BOTH members are
+        // enumerated directly (rs_next_common) instead of walking all nx*ny*nz cells — lanes of a wave would each
+        // enter the nested loops at different iterations and the wave would execute the whole nest.
+        // The stale masks come out of the structure: the x test is made once when an x-layer starts, the y test
+        // once per (x,y)-layer, the z test per cell, each from the state at that moment (in_x_layer / in_y_layer /
+        // in_z_layer); none is re-evaluated after a hit inside the layer.
+        for (int lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
+             lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1))
+            for (int ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
+                 ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1))
+                for (int lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
+                     lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1))
+                    if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr))
+                        moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, ((long long)lx * P.ny + ly) * P.nz + lz);
+    } else {
+        // Pore:522-530.  Along one axis a coordinate belongs to at most two overlapping cells k (one of each parity);
+        // they are found once per particle (rs_axis_k) and re-derived only after a hit moved the particles, instead of
+        // dividing 48 times per pair.  Membership itself is decided by the reference's own comparisons.
+        int k1[6], k2[6];
+        rs_pore_ks(A, p1, k1);
+        rs_pore_ks(A, p2, k2);
+        // Lanes of a wave hold different pairs whose first shared colour group differs; with the hit inside the group
+        // loop the wave would run the (large) collision path once per group.  So each lane first SEARCHES its next
+        // group with a shared cell (cheap integer work), then all lanes resolve together, then the search resumes.
+        int g = 0;
+        bool ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);      // unchanged until a hit moves the pair
+        for (;;) {
+            int hit_g = -1, hit_c = -1;
+            if (ov)
+                for (; g < 8; g++) {                                                        // Pore:522-524
+                    const int c1 = rs_pore_cell_k(P, k1, g);
+                    if (c1 >= 0 && c1 == rs_pore_cell_k(P, k2, g)) { hit_g = g; hit_c = c1; break; }
+                }
+            if (hit_g < 0) break;
+            if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16 + hit_g, hit_c)) {
+                moved = true;
+                rs_pore_ks(A, p1, k1);
+                rs_pore_ks(A, p2, k2);
+                ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);
+            }
+            g = hit_g + 1;
+        }
+    }
+    if (moved) {
+        rs_store_slot(A.W, sj, p1);
+        rs_store_slot(A.W, si, p2);
+    }
+}
+
+// ---- generic cluster (3+ members): literal emulation on the working set [b,e) ----------------------
+AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int wj, int wi, int phase, long long cell)
+{
+    if (!amc_overlap(K.x[wj], K.y[wj], K.z[wj], K.x[wi], K.y[wi], K.z[wi], A.P.collision_range)) return;
+    amc_particle p1 = rs_load_work(K, wj), p2 = rs_load_work(K, wi);
+    const int pj = K.pidx[wj], pi = K.pidx[wi];
+    if (rs_hit(A, sh, p1, p2, pj, pi, A.W.slot_of[pj], A.W.slot_of[pi], phase, cell)) {
+        rs_store_work(K, wj, p1);
+        rs_store_work(K, wi, p2);
+    }
+}
+
+AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
+{
+    const amc_params &P = A.P;
     if (P.geometry == AMC_GEOM_CELL) {
-        // one cell holding everything: Pore:168-169 loop order
-        for (int a = b + 1; a < e; a++)
-            for (int c = b; c < a; c++) rs_test_pair(A, sh, ord[c], ord[a], 16, 0);
+        for (int a = b + 1; a < e; a++)                                                     // Pore:168-169
+            for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
     } else if (P.geometry == AMC_GEOM_CUBE) {
-        // Cube:231-336 — masks are evaluated where the reference evaluates them
         for (int lx = 0; lx < P.nx; lx++) {
             const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;               // Cube:233
             int cnt = 0;
+            {   // skip ahead: no layer below floor(min x / dx) - 1 can hold a member
+                double vmin = K.x[b];
+                for (int a = b + 1; a < e; a++) vmin = K.x[a] < vmin ? K.x[a] : vmin;
+                const double f = floor(vmin / P.dx) - 1.0;
+                if (f > (double)lx && f < 1.0e9) { lx = (int)f - 1; continue; }
+            }
             for (int a = b; a < e; a++) {
-                const double v = W.sl_x[ord[a]];
+                const double v = K.x[a];
                 const int in = (xlo < v) && (v < xhi);
-                W.sl_tmp[ord[a]] = in;
+                K.tmp[a] = in;
                 cnt += in;
             }
             if (cnt < 2) continue;
@@ -115,63 +305,50 @@ AMC_DEV void rs_emulate(const rs_args &A, rs_shared *sh, int b, int e)
                 const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;           // Cube:235
                 cnt = 0;
                 for (int a = b; a < e; a++) {
-                    const int s = ord[a];
-                    int t = W.sl_tmp[s] & 1;
+                    int t = K.tmp[a] & 1;
                     if (t) {
-                        const double v = W.sl_y[s];
+                        const double v = K.y[a];
                         if ((ylo < v) && (v < yhi)) { t |= 2; cnt++; }
                     }
-                    W.sl_tmp[s] = t;
+                    K.tmp[a] = t;
                 }
                 if (cnt < 2) continue;
                 for (int lz = 0; lz < P.nz; lz++) {
                     const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;       // Cube:237
                     cnt = 0;
                     for (int a = b; a < e; a++) {
-                        const int s = ord[a];
-                        int t = W.sl_tmp[s] & 3;
+                        int t = K.tmp[a] & 3;
                         if (t == 3) {
-                            const double v = W.sl_z[s];
+                            const double v = K.z[a];
                             if ((zlo < v) && (v < zhi)) { t |= 4; cnt++; }
                         }
-                        W.sl_tmp[s] = t;
+                        K.tmp[a] = t;
                     }
                     if (cnt < 2) continue;
                     const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
                     for (int a = b + 1; a < e; a++) {
-                        if (W.sl_tmp[ord[a]] != 7) continue;
+                        if (K.tmp[a] != 7) continue;
                         for (int c = b; c < a; c++)
-                            if (W.sl_tmp[ord[c]] == 7) rs_test_pair(A, sh, ord[c], ord[a], 16, cell);
+                            if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
                     }
                 }
             }
         }
     } else {
-        // Pore:520-549 == Temp:813-842 — 8 colour groups, membership from the positions at the start of the group
-        const int nzl = P.nz / 2;
-        for (int g = 0; g < 8; g++) {
-            const int gx = g >> 2, gy = (g >> 1) & 1, gz = g & 1;                            // Pore:522-524
+        for (int g = 0; g < 8; g++) {                                                        // Pore:522-524
+            const int gx = g >> 2, gy = (g >> 1) & 1, gz = g & 1;
             int cnt = 0;
             for (int a = b; a < e; a++) {
-                const int s = ord[a];
-                int cell = -1;
-                const int lx = amc_axis_cell(W.sl_x[s], gx, P.nx, P.nx, P.dx, P.overlap_x);
-                if (lx >= 0) {
-                    const int ly = amc_axis_cell(W.sl_y[s], gy, P.ny, P.ny, P.dy, P.overlap_y);
-                    if (ly >= 0) {
-                        const int lz = amc_axis_cell(W.sl_z[s], gz, nzl, 0, P.dz, P.overlap_z);
-                        if (lz >= 0) cell = (lx * P.ny + ly) * nzl + lz;                     // Pore:530 list order
-                    }
-                }
-                W.sl_tmp[s] = cell;
+                const int cell = rs_pore_cell(P, K.x[a], K.y[a], K.z[a], gx, gy, gz);
+                K.tmp[a] = cell;
                 cnt += cell >= 0;
             }
             if (cnt < 2) continue;
             for (int a = b + 1; a < e; a++) {
-                const int ca = W.sl_tmp[ord[a]];
+                const int ca = K.tmp[a];
                 if (ca < 0) continue;
                 for (int c = b; c < a; c++)
-                    if (W.sl_tmp[ord[c]] == ca) rs_test_pair(A, sh, ord[c], ord[a], 16 + g, ca);
+                    if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
             }
         }
     }
@@ -195,13 +372,20 @@ AMC_DEV void rs_bitonic(unsigned long long *keys, int m)
     }
 }
 
-// get (or create) the slot of particle p; creation is published by the barrier that follows the phase
-AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int p)
+// slot bookkeeping: particle of the slot (global), cluster label = lowest slot id of the cluster and cluster size
+// (LDS when the sweep is small enough — the usual case — else the global work space)
+struct rs_slots {
+    int *p, *label, *size;
+    int cap;
+};
+
+// get (or create) the slot of particle p; creation is published by the barrier / kernel boundary that follows
+AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int cap, int p)
 {
     const int old = atomicCAS(&W.slot_of[p], -1, -2);
     if (old == -1) {
         const int s = atomicAdd(&sh->nslots, 1);
-        if (s < W.max_slots) {
+        if (s < cap) {
             W.sl_p[s] = p;
             W.slot_of[p] = s;
         } else {
@@ -211,6 +395,7 @@ AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int p)
     }
 }
 
+// merge request found by validation: particles pa, pb must be in one cluster (slot ids are filled in next round)
 AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
 {
     const int k = atomicAdd(&sh->nedges, 1);
@@ -218,171 +403,320 @@ AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
     sh->dirty = 1;
 }
 
+#define RS_VAL_BATCH 8         // neighbour entries fetched per validation batch
+
+// validation probe of history entry h: its position against every particle outside its cluster.  `cnt` are the
+// sweep counters (LDS inside a resolve kernel, W.ctl in the wide validate kernel), `label` the per-slot labels.
+AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const int *label, int ns, int cap, int h,
+                      double cr2i)
+{
+    const amc_resolve_ws &W = A.W;
+    const int sme = W.hist_slot[h];
+    const int pme = W.sl_p[sme];
+    const int lme = label[sme];
+    const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
+    // only the cells overlapped by the collision_range box around the new position can hold a partner (1.7 cells on
+    // average): fetch their bounds and overlay heads first, then the entries in batches
+    int cells[8], q0[8], q1[8], ovh[8];
+    const int ncell = amc_grid_box_cells(G, x, y, z, A.P.collision_range * 1.000001, cells);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        q0[k] = q1[k] = 0; ovh[k] = -1;
+        if (k < ncell) { q0[k] = A.B.cell_start[cells[k]]; q1[k] = A.B.cell_start[cells[k] + 1]; ovh[k] = W.ov_head[cells[k]]; }
+    }
+    int bq[RS_VAL_BATCH];
+    int nb = 0;
+    auto flush = [&]() {
+        double ex[RS_VAL_BATCH], ey[RS_VAL_BATCH], ez[RS_VAL_BATCH];
+        int bi[RS_VAL_BATCH];
+#pragma unroll
+        for (int k = 0; k < RS_VAL_BATCH; k++)
+            if (k < nb) { ex[k] = A.B.sx[bq[k]]; ey[k] = A.B.sy[bq[k]]; ez[k] = A.B.sz[bq[k]]; bi[k] = A.B.sidx[bq[k]]; }
+#pragma unroll
+        for (int k = 0; k < RS_VAL_BATCH; k++) {
+            if (k >= nb) continue;
+            const int idx = bi[k];
+            if (idx == pme) continue;
+            const double ax = ex[k] - x, ay = ey[k] - y, az = ez[k] - z;
+            if (ax * ax + ay * ay + az * az < cr2i) {
+                const int so = W.slot_of[idx];
+                if (so >= 0 && so < ns && label[so] == lme) continue;
+                if (so < 0) rs_claim_slot(W, cnt, cap, idx);
+                rs_add_edge(W, cnt, pme, idx);
+            }
+        }
+        nb = 0;
+    };
+    for (int k = 0; k < ncell; k++)
+        for (int q = q0[k]; q < q1[k]; q++) {
+            bq[nb++] = q;
+            if (nb == RS_VAL_BATCH) flush();
+        }
+    if (nb) flush();
+    // new positions of other clusters' members (overlay lists of the same cells)
+    for (int k = 0; k < ncell; k++)
+        for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
+            if (h2 == h) continue;
+            const int s2 = W.hist_slot[h2];
+            if (label[s2] == lme) continue;
+            const double ax = W.hist_x[h2] - x, ay = W.hist_y[h2] - y, az = W.hist_z[h2] - z;
+            if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
+        }
+}
+
+AMC_DEV int rs_hist_cell(const rs_args &A, const amc_grid &G, int h)
+{
+    int cx, cy, cz;
+    amc_grid_coords(G, A.W.hist_x[h], A.W.hist_y[h], A.W.hist_z[h], cx, cy, cz);
+    return amc_grid_cell(G, cx, cy, cz, nullptr);
+}
+
+#define RS_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        if (A.dbg && tid == 0) {                                                           \
+            const long long now__ = wall_clock64();                                        \
+            A.dbg[slot] += now__ - t_last;                                                 \
+            t_last = now__;                                                                \
+        }                                                                                  \
+    } while (0)
+
+#define RS_NS 2048             // slot labels / sizes kept in LDS
+#define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
+
+// MODE 0: first round only (claim, label, emulate), validation + commit are the wide kernels that follow
+// MODE 1: continuation: if the wide validation found merges, run the remaining rounds (validation in-kernel)
+// MODE 2: everything in one kernel incl. brute-force validation and commit (no detection grid: single cells, small N)
+template <int GEOM, int MODE>
 __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
+    long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     __shared__ rs_shared sh;
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
+    __shared__ double pool_d[10][RS_POOL];
+    __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL];
+    __shared__ uint8_t pool_flag[RS_POOL], pool_moved[RS_POOL];
+    __shared__ int s_label[RS_NS], s_size[RS_NS];
+    __shared__ int s_lay[RS_LAY];
     const amc_resolve_ws &W = A.W;
     const int tid = threadIdx.x;
     amc_dev_counters *cnt = A.O.cnt;
-    int ncand = (int)cnt->cand_count;
-    if (ncand > W.max_cand) ncand = W.max_cand;
-    if (tid == 0) {
-        sh.nslots = 0; sh.nedges = 0; sh.nhist = 0; sh.nev = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0; sh.nfp = 0;
-        sh.ovf = 0; sh.nclusters = 0;
+    rs_shared *ctl = (rs_shared *)W.ctl;
+    int ncand;
+    if (MODE == 1) {
+        if (tid == 0) sh = *ctl;
+        __syncthreads();
+        if (!sh.active || !sh.dirty || sh.ovf) return;      // the first round validated (or nothing to do)
+        ncand = sh.ncand;
+    } else {
+        ncand = (int)cnt->cand_count;
+        if (ncand > W.max_cand) ncand = W.max_cand;
+        __syncthreads();
+        if (tid == 0) {
+            sh.nslots = 0; sh.nedges = 0; sh.nhist = 0; sh.nev = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
+            sh.nfp = 0; sh.ovf = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
+            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0;
+            cnt->cand_count = 0;
+            if (ncand == 0) *ctl = sh;
+        }
+        __syncthreads();
+        if (ncand == 0) return;     // uniform: nothing to resolve this sweep
     }
-    __syncthreads();
-    if (ncand == 0) return;     // uniform: nothing to resolve this sweep
 
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
-
-    // ---- slots for the candidate endpoints ----------------------------------------------------------------------
-    for (int k = tid; k < ncand; k += RS_T) {
-        rs_claim_slot(W, &sh, W.cand_i[k]);
-        rs_claim_slot(W, &sh, W.cand_j[k]);
+    rs_slots V;
+    V.p = W.sl_p;
+    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS; }
+    else { V.label = W.sl_label; V.size = W.sl_tmp; V.cap = W.max_slots; }
+    // grid layer tables -> LDS (every validation probe reads them)
+    amc_grid G = A.G;
+    if (MODE != 0 && !A.allpairs && 3 * G.gz <= RS_LAY) {
+        for (int k = tid; k < 3 * G.gz; k += RS_T) s_lay[k] = A.G.lay_lo[k];     // the three tables are contiguous
+        G.lay_lo = s_lay; G.lay_n = s_lay + G.gz; G.lay_off = s_lay + 2 * G.gz;
     }
     __syncthreads();
 
-    int rounds = 0;
+    if (MODE != 1) {
+        // ---- slots for the candidate endpoints; candidates become slot pairs -------------------------------------------
+        for (int k = tid; k < ncand; k += RS_T) {
+            rs_claim_slot(W, &sh, V.cap, W.cand_i[k]);
+            rs_claim_slot(W, &sh, V.cap, W.cand_j[k]);
+        }
+        __syncthreads();
+        for (int k = tid; k < ncand; k += RS_T) {
+            W.cand_si[k] = W.slot_of[W.cand_i[k]];
+            W.cand_sj[k] = W.slot_of[W.cand_j[k]];
+        }
+        __syncthreads();
+    } else {
+        // the overlay still holds the first round's entries: clear it before this kernel's own rounds
+        const int nh0 = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+        for (int h = tid; h < nh0; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
+        __syncthreads();
+    }
+    RS_STAMP(0);
+
+    int rounds = sh.rounds;
+    int edges_done = sh.edges_done;     // edges [0, edges_done) already hold slot ids
     for (;;) {
         rounds++;
-        const int ns = sh.nslots < W.max_slots ? sh.nslots : W.max_slots;
+        const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
         const int nedges = sh.nedges < W.max_edges ? sh.nedges : W.max_edges;
         __syncthreads();
-        // ---- (re)load the scratch state from the untouched particle arrays; labels = own particle index --------
+        // ---- per-round reset; new merge edges: particle ids -> slot ids -------------------------------------------------
         for (int s = tid; s < ns; s += RS_T) {
-            const int p = W.sl_p[s];
-            W.sl_x[s] = A.S.x[p]; W.sl_y[s] = A.S.y[p]; W.sl_z[s] = A.S.z[p];
-            W.sl_vx[s] = A.S.vx[p]; W.sl_vy[s] = A.S.vy[p]; W.sl_vz[s] = A.S.vz[p];
-            W.sl_d[s] = A.S.d[p]; W.sl_dx[s] = A.S.dx[p]; W.sl_dy[s] = A.S.dy[p]; W.sl_dz[s] = A.S.dz[p];
-            W.sl_flag[s] = A.S.flag[p];
             W.sl_moved[s] = 0;
-            W.sl_label[s] = p;
+            V.label[s] = s;
+            V.size[s] = 0;
         }
-        if (tid == 0) { sh.nhist = 0; sh.nev = 0; sh.nhits = 0; sh.nfp = 0; sh.dirty = 0; sh.nclusters = 0; }
+        for (int k = edges_done + tid; k < nedges; k += RS_T) {
+            W.edge_a[k] = W.slot_of[W.edge_a[k]];
+            W.edge_b[k] = W.slot_of[W.edge_b[k]];
+        }
+        edges_done = nedges;
+        if (tid == 0) { sh.nhist = 0; sh.nev = 0; sh.nhits = 0; sh.nfp = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; }
         __syncthreads();
-        // ---- connected components by label propagation (label = lowest particle index of the cluster) ------------
+        // ---- connected components by label propagation (label = lowest slot id of the cluster) -------------------------
         for (;;) {
-            if (tid == 0) sh.changed = 0;
-            __syncthreads();
+            int changed = 0;
             for (int k = tid; k < ncand + nedges; k += RS_T) {
-                const int pa = k < ncand ? W.cand_i[k] : W.edge_a[k - ncand];
-                const int pb = k < ncand ? W.cand_j[k] : W.edge_b[k - ncand];
-                const int sa = W.slot_of[pa], sb = W.slot_of[pb];
-                if (sa < 0 || sb < 0) continue;
-                const int la = W.sl_label[sa], lb = W.sl_label[sb];
-                if (la < lb) { atomicMin(&W.sl_label[sb], la); sh.changed = 1; }
-                else if (lb < la) { atomicMin(&W.sl_label[sa], lb); sh.changed = 1; }
+                const int sa = k < ncand ? W.cand_si[k] : W.edge_a[k - ncand];
+                const int sb = k < ncand ? W.cand_sj[k] : W.edge_b[k - ncand];
+                if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
+                const int la = V.label[sa], lb = V.label[sb];
+                if (la < lb) { atomicMin(&V.label[sb], la); changed = 1; }
+                else if (lb < la) { atomicMin(&V.label[sa], lb); changed = 1; }
+            }
+            if (!__syncthreads_or(changed)) break;
+        }
+        // ---- cluster sizes, accumulated on the label slot ------------------------------------------------------------------
+        for (int s = tid; s < ns; s += RS_T) atomicAdd(&V.size[V.label[s]], 1);
+        __syncthreads();
+        RS_STAMP(1);
+        // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
+        unsigned long long *keys = lds_keys;
+        for (int s = tid; s < ns; s += RS_T) {
+            if (V.label[s] == s) atomicAdd(&sh.nclusters, 1);
+            if (V.size[V.label[s]] >= 3) {
+                const int k = atomicAdd(&sh.ncomplex, 1);
+                const unsigned long long key = ((unsigned long long)(unsigned)V.label[s] << 32) | (unsigned)V.p[s];
+                if (k < RS_SORT_LDS) keys[k] = key; else W.sl_key[k] = key;
+            }
+        }
+        RS_STAMP(6);
+        // ---- two-particle clusters straight from the candidate list, both particles in registers ----------------------------
+        for (int k = tid; k < ncand; k += RS_T) {
+            const int si = W.cand_si[k], sj = W.cand_sj[k];
+            if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
+            if (V.size[V.label[si]] != 2) continue;
+            rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
+        }
+        RS_STAMP(7);
+        __syncthreads();
+        RS_STAMP(2);
+        // ---- larger clusters: sort members by (label, index), working set in LDS when it fits ----------------------------
+        const int nc = sh.ncomplex;
+        if (nc > 0) {
+            int m = 1;
+            while (m < nc) m <<= 1;
+            if (nc > RS_SORT_LDS) {
+                for (int k = tid; k < RS_SORT_LDS; k += RS_T) W.sl_key[k] = lds_keys[k];
+                keys = W.sl_key;
+            }
+            for (int k = nc + tid; k < m; k += RS_T) keys[k] = ~0ULL;
+            __syncthreads();
+            rs_bitonic(keys, m);
+            rs_work K;
+            if (nc <= RS_POOL) {
+                K.x = pool_d[0]; K.y = pool_d[1]; K.z = pool_d[2]; K.vx = pool_d[3]; K.vy = pool_d[4]; K.vz = pool_d[5];
+                K.d = pool_d[6]; K.dx = pool_d[7]; K.dy = pool_d[8]; K.dz = pool_d[9];
+                K.tmp = pool_tmp; K.pidx = pool_pidx; K.flag = pool_flag; K.moved = pool_moved;
+            } else {
+                K.x = W.cw_d[0]; K.y = W.cw_d[1]; K.z = W.cw_d[2]; K.vx = W.cw_d[3]; K.vy = W.cw_d[4]; K.vz = W.cw_d[5];
+                K.d = W.cw_d[6]; K.dx = W.cw_d[7]; K.dy = W.cw_d[8]; K.dz = W.cw_d[9];
+                K.tmp = W.cw_tmp; K.pidx = W.cw_pidx; K.flag = W.cw_flag; K.moved = W.cw_moved;
+            }
+            for (int w = tid; w < nc; w += RS_T) {
+                const int p = (int)(keys[w] & 0xffffffffULL);
+                const amc_particle q = rs_load_particle(A.S, p);
+                rs_store_work(K, w, q);
+                K.moved[w] = 0;
+                K.pidx[w] = p;
             }
             __syncthreads();
-            if (!sh.changed) break;
+            for (int w = tid; w < nc; w += RS_T) {
+                const unsigned lab = (unsigned)(keys[w] >> 32);
+                if (w > 0 && (unsigned)(keys[w - 1] >> 32) == lab) continue;      // not a cluster head
+                int e = w + 1;
+                while (e < nc && (unsigned)(keys[e] >> 32) == lab) e++;
+                if (e - w >= 2) rs_emulate_generic(A, &sh, K, w, e);
+            }
             __syncthreads();
-        }
-        // ---- order the slots by (label, particle index) -------------------------------------------------------------
-        int m = 1;
-        while (m < ns) m <<= 1;
-        unsigned long long *keys = (m <= RS_SORT_LDS) ? lds_keys : W.sl_key;
-        for (int s = tid; s < m; s += RS_T)
-            keys[s] = (s < ns) ? (((unsigned long long)(unsigned)W.sl_label[s] << 32) | (unsigned)W.sl_p[s]) : ~0ULL;
-        __syncthreads();
-        rs_bitonic(keys, m);
-        for (int r = tid; r < ns; r += RS_T) W.order[r] = W.slot_of[(int)(keys[r] & 0xffffffffULL)];
-        __syncthreads();
-        // ---- emulate every cluster -------------------------------------------------------------------------------
-        for (int r = tid; r < ns; r += RS_T) {
-            const int lab = W.sl_label[W.order[r]];
-            if (r > 0 && W.sl_label[W.order[r - 1]] == lab) continue;     // not a cluster head
-            int e = r + 1;
-            while (e < ns && W.sl_label[W.order[e]] == lab) e++;
-            atomicAdd(&sh.nclusters, 1);
-            if (e - r >= 2) rs_emulate(A, &sh, r, e);
+            for (int w = tid; w < nc; w += RS_T)
+                if (K.moved[w]) rs_store_slot(W, W.slot_of[K.pidx[w]], rs_load_work(K, w));
         }
         __syncthreads();
-        // ---- validate ------------------------------------------------------------------------------------------------
+        RS_STAMP(3);
         const int nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+        if (MODE == 0) {
+            // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
+            if (V.label != W.sl_label)
+                for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
+            for (int h = tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            __syncthreads();
+            if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.nslots0 = ns; *ctl = sh; }
+            RS_STAMP(4);
+            if (A.dbg && tid == 0) { A.dbg[8] += 1; A.dbg[9] += ncand; A.dbg[10] += sh.ncomplex; A.dbg[11] += 1; }
+            return;
+        }
+        // ---- validate: every new position against everything outside its cluster ------------------------------------------------
         if (!A.allpairs) {
-            // overlay: history entries hashed into their grid cell
-            for (int h = tid; h < nh; h += RS_T) {
-                int cx, cy, cz;
-                amc_grid_coords(A.G, W.hist_x[h], W.hist_y[h], W.hist_z[h], cx, cy, cz);
-                const int c = amc_grid_cell(A.G, cx, cy, cz, nullptr);
-                W.ov_next[h] = atomicExch(&W.ov_head[c], h);
-            }
+            for (int h = tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
-            for (int h = tid; h < nh; h += RS_T) {
-                const int sme = W.hist_slot[h];
-                const int pme = W.sl_p[sme];
-                const int lme = W.sl_label[sme];
-                const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
-                int cx, cy, cz;
-                amc_grid_coords(A.G, x, y, z, cx, cy, cz);
-                for (int dz = -1; dz <= 1; dz++)
-                    for (int dy = -1; dy <= 1; dy++) {
-                        int c_lo, c_hi;
-                        if (!amc_grid_row(A.G, cx, cy + dy, cz + dz, c_lo, c_hi)) continue;
-                        // pre-sweep positions of every particle stored in these cells
-                        const int q1 = A.B.cell_start[c_hi + 1];
-                        for (int q = A.B.cell_start[c_lo]; q < q1; q++) {
-                            const int idx = A.B.sidx[q];
-                            if (idx == pme) continue;
-                            const double ex = A.B.sx[q] - x, ey = A.B.sy[q] - y, ez = A.B.sz[q] - z;
-                            if (ex * ex + ey * ey + ez * ez < cr2i) {
-                                const int so = W.slot_of[idx];
-                                if (so >= 0 && so < ns && W.sl_label[so] == lme) continue;
-                                if (so < 0) rs_claim_slot(W, &sh, idx);
-                                rs_add_edge(W, &sh, pme, idx);
-                            }
-                        }
-                        // new positions of other clusters' members
-                        for (int c = c_lo; c <= c_hi; c++)
-                            for (int h2 = W.ov_head[c]; h2 >= 0; h2 = W.ov_next[h2]) {
-                                const int s2 = W.hist_slot[h2];
-                                if (W.sl_label[s2] == lme) continue;
-                                const double ex = W.hist_x[h2] - x, ey = W.hist_y[h2] - y, ez = W.hist_z[h2] - z;
-                                if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, pme, W.sl_p[s2]);
-                            }
-                    }
-            }
+            for (int h = tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);
             __syncthreads();
-            for (int h = tid; h < nh; h += RS_T) {
-                int cx, cy, cz;
-                amc_grid_coords(A.G, W.hist_x[h], W.hist_y[h], W.hist_z[h], cx, cy, cz);
-                W.ov_head[amc_grid_cell(A.G, cx, cy, cz, nullptr)] = -1;
-            }
+            for (int h = tid; h < nh; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
         } else {
             // no grid (single cell / small N): brute force against all particles and all history entries
             for (long long w = tid; w < (long long)nh * A.n; w += RS_T) {
                 const int h = (int)(w / A.n);
                 const int idx = (int)(w % A.n);
                 const int sme = W.hist_slot[h];
-                if (idx == W.sl_p[sme]) continue;
+                if (idx == V.p[sme]) continue;
                 const double ex = A.S.x[idx] - W.hist_x[h], ey = A.S.y[idx] - W.hist_y[h], ez = A.S.z[idx] - W.hist_z[h];
                 if (ex * ex + ey * ey + ez * ez < cr2i) {
                     const int so = W.slot_of[idx];
-                    if (so >= 0 && so < ns && W.sl_label[so] == W.sl_label[sme]) continue;
-                    if (so < 0) rs_claim_slot(W, &sh, idx);
-                    rs_add_edge(W, &sh, W.sl_p[sme], idx);
+                    if (so >= 0 && so < ns && V.label[so] == V.label[sme]) continue;
+                    if (so < 0) rs_claim_slot(W, &sh, V.cap, idx);
+                    rs_add_edge(W, &sh, V.p[sme], idx);
                 }
             }
             for (long long w = tid; w < (long long)nh * nh; w += RS_T) {
                 const int h = (int)(w / nh), h2 = (int)(w % nh);
                 if (h2 >= h) continue;
                 const int s1 = W.hist_slot[h], s2 = W.hist_slot[h2];
-                if (W.sl_label[s1] == W.sl_label[s2]) continue;
+                if (V.label[s1] == V.label[s2]) continue;
                 const double ex = W.hist_x[h2] - W.hist_x[h], ey = W.hist_y[h2] - W.hist_y[h], ez = W.hist_z[h2] - W.hist_z[h];
-                if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, W.sl_p[s1], W.sl_p[s2]);
+                if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, V.p[s1], V.p[s2]);
             }
         }
         __syncthreads();
+        RS_STAMP(4);
         if (!sh.dirty || sh.ovf || rounds >= RS_MAX_ROUNDS) break;
         __syncthreads();
     }
 
-    // ---- commit --------------------------------------------------------------------------------------------------
-    const int ns = sh.nslots < W.max_slots ? sh.nslots : W.max_slots;
     const bool ok = !sh.ovf && !(sh.dirty && rounds >= RS_MAX_ROUNDS);
+    if (MODE == 1) {
+        // the wide commit kernel finishes the sweep
+        __syncthreads();
+        if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.ok = ok; sh.dirty = 0; sh.nhist = 0; *ctl = sh; }
+        if (A.dbg && tid == 0) { A.dbg[8] += rounds - 1; A.dbg[12] += 1; }
+        return;
+    }
+    // ---- commit (MODE 2) -------------------------------------------------------------------------------------------------
+    const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
     for (int s = tid; s < ns; s += RS_T) {
-        const int p = W.sl_p[s];
+        const int p = V.p[s];
         if (ok && W.sl_moved[s]) {
             A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
             A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
@@ -398,7 +732,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                      W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
     }
     __syncthreads();
+    RS_STAMP(5);
     if (tid == 0) {
+        if (A.dbg) { A.dbg[8] += rounds; A.dbg[9] += ncand; A.dbg[10] += sh.ncomplex; A.dbg[11] += 1; }
         cnt->n_candidates += (unsigned long long)ncand;
         cnt->n_clusters += (unsigned long long)sh.nclusters;
         cnt->n_rounds += (unsigned long long)rounds;
@@ -408,16 +744,90 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         } else {
             cnt->flags |= 4ULL;
         }
-        cnt->cand_count = 0;
+        sh.active = 0;
+        *ctl = sh;
     }
+}
+
+// ---- wide kernels around the single-workgroup resolve (grid mode) ---------------------------------------------------------
+// validation of the first round: one thread per history entry, spread over the chip (the probes are scattered reads,
+// and one CU sustains only ~85 outstanding misses per microsecond)
+__global__ __launch_bounds__(64) void k_validate(rs_args A)
+{
+    rs_shared *ctl = (rs_shared *)A.W.ctl;
+    if (!ctl->active || ctl->ovf) return;
+    const int nh = ctl->nhist < A.W.max_hist ? ctl->nhist : A.W.max_hist;
+    const int ns = ctl->nslots0;        // slots that existed when the labels were written
+    const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
+    for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
+        rs_probe(A, A.G, ctl, A.W.sl_label, ns, A.W.max_slots, h, cr2i);
+}
+
+// commit: scratch state -> particle arrays, completed paths -> histogram / records, counters; clears the overlay
+__global__ __launch_bounds__(256) void k_commit(rs_args A)
+{
+    const amc_resolve_ws &W = A.W;
+    const rs_shared *ctl = (const rs_shared *)W.ctl;
+    if (!ctl->active) return;
+    const bool ok = ctl->ok && !ctl->ovf;
+    const int ns = ctl->nslots < W.max_slots ? ctl->nslots : W.max_slots;
+    const int nev = ctl->nev < W.max_events ? ctl->nev : W.max_events;
+    const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    for (int s = gtid; s < ns; s += gstride) {
+        const int p = W.sl_p[s];
+        if (ok && W.sl_moved[s]) {
+            A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
+            A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
+            A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
+            A.S.flag[p] = W.sl_flag[s];
+        }
+        W.slot_of[p] = -1;
+    }
+    if (ok)
+        for (int e = gtid; e < nev; e += gstride)
+            amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
+                     W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
+    for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // first-round overlay, if still set
+    if (gtid == 0) {
+        amc_dev_counters *cnt = A.O.cnt;
+        cnt->n_candidates += (unsigned long long)ctl->ncand;
+        cnt->n_clusters += (unsigned long long)ctl->nclusters;
+        cnt->n_rounds += (unsigned long long)ctl->rounds;
+        if (ok) {
+            cnt->n_pp += (unsigned long long)ctl->nhits;
+            cnt->n_fp_errors += (unsigned long long)ctl->nfp;
+        } else {
+            cnt->flags |= 4ULL;
+        }
+    }
+}
+
+template <int GEOM>
+static void rs_launch_all(amc_ctx *c, const rs_args &A)
+{
+    if (c->allpairs) {
+        hipLaunchKernelGGL((k_resolve<GEOM, 2>), dim3(1), dim3(RS_T), 0, c->stream, A);
+        return;
+    }
+    hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
+    hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
 }
 
 hipError_t amc_launch_resolve(amc_ctx *c)
 {
     rs_args A;
     A.P = c->P; A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
+    A.dbg = c->d_dbg;
+    A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;
     amc_prof_begin(c, AMC_K_RESOLVE);
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(RS_T), 0, c->stream, A);
+    switch (c->P.geometry) {
+    case AMC_GEOM_CELL: rs_launch_all<AMC_GEOM_CELL>(c, A); break;
+    case AMC_GEOM_CUBE: rs_launch_all<AMC_GEOM_CUBE>(c, A); break;
+    default: rs_launch_all<AMC_GEOM_PORE>(c, A); break;
+    }
     amc_prof_end(c);
     return hipGetLastError();
 }

@@ -53,6 +53,7 @@ def _common(p: AmcParams, ph, n, device=0):
 class SimConstants(dict):
     """dict of derived host-side constants (dt, a_shape, region populations ...) next to the C struct."""
     __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
 
 
 def cell_params(sigma=SIGMA, n=0, device=0):

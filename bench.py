@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — particle-steps/s of the hot path (drift -> walls -> bounds -> p-p sweep) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cube_1e5|pore_5e5|pore_1e6|cube_1e6]
+
+A "step" is one full timestep(dt) over all particles (BASELINE.json metric: particle-steps/sec + achieved HBM GB/s).
+At N=1 the default workload is BASELINE configs[1]: Open_Air_Cube_MC geometry, N = 100,000 synthetic uniform-cube
+argon.  State is resident in HBM before the timed region starts.  For N>1 the driver launches
+one rank per GPU through torch.distributed.run; particles are sharded by index range with a per-step all-gather of
+positions (argon_monte_carlo_amd/dist.py) and per-GPU work is fixed (weak scaling).
+
+Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel, HIP-event timed on the
+launch stream) and `cpu_baseline` (the C oracle = single-thread port of the reference algorithm, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+BYTES_PER_PARTICLE_STEP = 137    # 81 B read + 56 B written by a complete timestep(dt)
+# algorithmic bytes per particle for each kernel class (DESIGN.md "kernels")
+ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 24, "bounds": 24}
+
+WORKLOADS = {
+    "cube_1e5": ("cube", 100_000),
+    "cube_1e6": ("cube", 1_000_000),
+    "pore_5e5": ("pore", 500_000),
+    "pore_1e6": ("pore", 1_000_000),
+}
+
+
+def make_workload(name, n_override=None, device=0):
+    from argon_monte_carlo_amd import ic as IC
+    from argon_monte_carlo_amd import params as PR
+    kind, n = WORKLOADS[name]
+    if n_override:
+        n = n_override
+    if kind == "cube":
+        p, c = PR.cube_params_for_n(n, device=device)
+        init = IC.cube_ic(p, c, seed=127)
+    else:
+        p, c = PR.pore_params(n=n, device=device)
+        init = IC.pore_ic(p, c, seed=17)
+    # count-and-continue on a degenerate wall/contact solve (Temp:340-342 semantics) instead of aborting like Pore:336-338
+    p.reserved1 = 1
+    return p, c, init
+
+
+def cpu_baseline(workload, budget_s=12.0):
+    """The oracle (oracle/amc_oracle.c, `mul` variant) on one host core, on a bounded number of steps of the SAME
+    workload.  Reported next to the GPU number; it is a baseline, not the target."""
+    from oracle import oracle as O
+    p, c, init = make_workload(workload)
+    orc = O.Oracle(p, mode="mul")
+    orc.upload(*init)
+    orc.timestep(c["dt"])                       # warm-up (page faults)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        orc.timestep(c["dt"])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or steps >= 2000:
+            break
+    return {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle/amc_oracle.c single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="cube_1e5", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=0, help="override the particle count per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from argon_monte_carlo_amd.engine import Engine
+
+    kind, n_per_gpu = WORKLOADS[args.workload]
+    if args.n:
+        n_per_gpu = args.n
+    stream_ptr = torch.cuda.current_stream().cuda_stream
+
+    if world == 1:
+        p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
+        eng = Engine(p)
+        eng.set_stream(stream_ptr)
+        eng.upload(*init)
+        step = lambda k: eng.run(c["dt"], k)          # noqa: E731
+        n_total = int(p.n)
+        parallelism = "single GPU"
+        engines = [eng]
+    else:
+        from argon_monte_carlo_amd.dist import ShardedSimulation
+        n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
+        p, c, init = make_workload(args.workload, n_total, device=local_rank)
+        sim = ShardedSimulation(p, rank, world, backend="nccl", stream_ptr=stream_ptr)
+        sim.upload(*init)
+        step = lambda k: sim.run(c["dt"], k)          # noqa: E731
+        parallelism = f"index-range shards x{world}, per-step all-gather of positions (RCCL)"
+        engines = [sim.engine]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    step(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    stats = step(args.steps)
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # per-kernel durations: the same K steps again with every launch bracketed by hipEvents on the launch stream
+    eng0 = engines[0]
+    eng0.profile(True)
+    step(args.steps)
+    sync()
+    kt = eng0.kernel_times()
+    eng0.profile(False)
+
+    if rank == 0:
+        value = n_total * args.steps / el
+        n_local = n_total // world if world > 1 else n_total
+        dom = max(((k, v) for k, v in kt.items() if v[1] > 0), key=lambda kv: kv[1][0], default=(None, (0, 0)))
+        roof = None
+        if dom[0] is not None:
+            k, (ms, cnt) = dom
+            avg_s = ms / cnt * 1e-3
+            per_particle = ALGO_BYTES.get(k, 24)
+            units = n_local if k in ("drift_walls", "bounds") else n_total
+            ach = per_particle * units / avg_s / 1e9
+            roof = {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                    "algorithmic_bytes_per_launch": per_particle * units,
+                    "per_kernel_avg_us": {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]},
+                    "whole_step_frac_of_hbm_peak": BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
+        out = {
+            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "geometry": kind, "n_particles": n_total, "n_per_gpu": n_local,
+                       "dt": c["dt"], "parallelism": parallelism,
+                       "pp_collisions_per_step": stats["n_pp"] / args.steps if stats else None},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
