@@ -69,8 +69,8 @@ class AmcPathRecord(C.Structure):
 
 
 class AmcDeviceView(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("xchg_send", C.c_void_p),
-                ("xchg_recv", C.c_void_p), ("xchg_stride", C.c_int64), ("xchg_record_bytes", C.c_int64)]
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("xchg", C.c_void_p),
+                ("xchg_capacity", C.c_int64), ("n", C.c_int64), ("lo", C.c_int64), ("hi", C.c_int64)]
 
 
 # numpy dtype with the same layout as amc_path_record

@@ -46,10 +46,14 @@ SIGNATURES = {
     "amc_histograms": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "amc_reset_outputs": (C.c_int, [_ctx]),
     "amc_set_shard": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
-    "amc_device_view_get": (C.c_int, [_ctx, C.c_int, C.POINTER(AmcDeviceView)]),
+    "amc_device_view_get": (C.c_int, [_ctx, C.POINTER(AmcDeviceView)]),
     "amc_mg_local": (C.c_int, [_ctx, C.c_double]),
-    "amc_mg_detect_pack": (C.c_int, [_ctx, _i64p]),
-    "amc_mg_resolve": (C.c_int, [_ctx, C.c_int, _i64p, C.POINTER(AmcStepStats)]),
+    "amc_mg_detect": (C.c_int, [_ctx, _i64p]),
+    "amc_mg_candidates": (C.c_int, [_ctx, _i32p, _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_mg_pack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
+    "amc_mg_unpack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
+    "amc_mg_resolve_round": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_mg_commit": (C.c_int, [_ctx]),
     "amc_mg_finish": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_profile": (C.c_int, [_ctx, C.c_int]),
     "amc_kernel_times": (C.c_int, [_ctx, _dp, _i64p]),

@@ -206,6 +206,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
+    c->mg_count_pp = true;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
     c->stream = nullptr;
     int rc = AMC_OK;
@@ -652,12 +653,140 @@ int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
 {
     if (!c || lo < 0 || hi < lo || hi > c->n) return AMC_ERR_INVALID;
     c->lo = lo; c->hi = hi;
+    c->mg_count_pp = (lo == 0);     // the rank that owns particle 0 reports the sweep's collision count
     return AMC_OK;
 }
-int amc_device_view_get(amc_ctx *c, int, amc_device_view *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
-int amc_mg_local(amc_ctx *c, double) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
-int amc_mg_detect_pack(amc_ctx *c, int64_t *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
-int amc_mg_resolve(amc_ctx *c, int, const int64_t *, amc_step_stats *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
-int amc_mg_finish(amc_ctx *c, amc_step_stats *) { return amc_fail(c, AMC_ERR_INVALID, "multi-GPU: not implemented yet"); }
+
+static int mg_ensure_xchg(amc_ctx *c)
+{
+    if (c->xchg_send) return AMC_OK;
+    c->xchg_stride = std::max<int64_t>(c->W.max_slots, 1024);
+    AMC_HIP(c, hipMalloc(&c->xchg_send, sizeof(double) * 11 * (size_t)c->xchg_stride));
+    AMC_HIP(c, hipMalloc(&c->xchg_recv, sizeof(int) * (size_t)c->xchg_stride));
+    return AMC_OK;
+}
+
+int amc_device_view_get(amc_ctx *c, amc_device_view *out)
+{
+    if (!c || !out) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = mg_ensure_xchg(c);
+    if (rc) return rc;
+    out->x = c->S.x; out->y = c->S.y; out->z = c->S.z;
+    out->xchg = c->xchg_send; out->xchg_capacity = c->xchg_stride;
+    out->n = c->n; out->lo = c->lo; out->hi = c->hi;
+    return AMC_OK;
+}
+
+int amc_mg_local(amc_ctx *c, double dt)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (c->allpairs || c->P.geometry == AMC_GEOM_CELL || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
+        return amc_fail(c, AMC_ERR_INVALID, "multi-GPU needs the binned detector and the cube / specular pore geometry");
+    AMC_HIP(c, hipSetDevice(c->device));
+    const int st = (c->P.geometry == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
+    AMC_HIP(c, amc_launch_stream(c, dt, st, 0));
+    return AMC_OK;
+}
+
+int amc_mg_detect(amc_ctx *c, int64_t *n_candidates)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_bin(c));
+    AMC_HIP(c, amc_launch_detect(c));
+    amc_dev_counters now;
+    int rc = read_counters(c, &now);
+    if (rc) return rc;
+    if (now.cand_count > (unsigned)c->W.max_cand) return amc_fail(c, AMC_ERR_CAPACITY, "candidate list overflow (%u)", now.cand_count);
+    if (n_candidates) *n_candidates = now.cand_count;
+    return AMC_OK;
+}
+
+int amc_mg_candidates(amc_ctx *c, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n)
+{
+    if (!c || !n) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_dev_counters now;
+    int rc = read_counters(c, &now);
+    if (rc) return rc;
+    const size_t k = std::min<size_t>(now.cand_count, (size_t)c->W.max_cand);
+    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "amc_mg_candidates: %zu pairs, buffer holds %zu", k, cap);
+    if (k) {
+        AMC_HIP(c, hipMemcpyAsync(cand_i, c->W.cand_i, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipMemcpyAsync(cand_j, c->W.cand_j, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *n = k;
+    return AMC_OK;
+}
+
+static int mg_upload_list(amc_ctx *c, const int32_t *particles, size_t n)
+{
+    int rc = mg_ensure_xchg(c);
+    if (rc) return rc;
+    if ((int64_t)n > c->xchg_stride) return amc_fail(c, AMC_ERR_CAPACITY, "exchange list of %zu particles exceeds capacity %lld", n, (long long)c->xchg_stride);
+    if (n) AMC_HIP(c, hipMemcpyAsync(c->xchg_recv, particles, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    return AMC_OK;
+}
+
+int amc_mg_pack_state(amc_ctx *c, const int32_t *particles, size_t n)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = mg_upload_list(c, particles, n);
+    if (rc) return rc;
+    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 0));
+    return AMC_OK;
+}
+
+int amc_mg_unpack_state(amc_ctx *c, const int32_t *particles, size_t n)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = mg_upload_list(c, particles, n);
+    if (rc) return rc;
+    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 1));
+    return AMC_OK;
+}
+
+int amc_mg_resolve_round(amc_ctx *c, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new)
+{
+    if (!c || !dirty || !n_new) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_resolve_round(c, first));
+    amc_resolve_ctl ctl;
+    AMC_HIP(c, hipMemcpyAsync(&ctl, c->W.ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    *dirty = 0; *n_new = 0;
+    if (!ctl.active) return AMC_OK;
+    if (ctl.ovf) return amc_fail(c, AMC_ERR_CAPACITY, "resolve work space overflow");
+    *dirty = ctl.dirty != 0;
+    const int k = ctl.nslots - ctl.nslots0;
+    if (k > 0) {
+        if ((size_t)k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d new cluster members, buffer holds %zu", k, cap);
+        AMC_HIP(c, hipMemcpy(new_members, c->W.sl_p + ctl.nslots0, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost));
+        std::sort(new_members, new_members + k);
+        *n_new = (size_t)k;
+    }
+    return AMC_OK;
+}
+
+int amc_mg_commit(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_commit(c));
+    return AMC_OK;
+}
+
+int amc_mg_finish(amc_ctx *c, amc_step_stats *out)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (c->P.geometry == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));
+    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    return finish_stats(c, out);
+}
 
 }  // extern "C"

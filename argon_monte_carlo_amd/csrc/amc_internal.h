@@ -97,8 +97,9 @@ struct amc_ctx {
     std::vector<std::pair<int, int>> ev_pending;   // (kernel class, pool index)
     size_t ev_used;
     // multi-GPU exchange
-    void *xchg_send, *xchg_recv;
-    int64_t xchg_stride;
+    void *xchg_send, *xchg_recv;   // xchg_send = state table float64[11][n_list]; xchg_recv = int32 particle list
+    int64_t xchg_stride;           // capacity of both, in particles
+    bool mg_count_pp;              // this rank adds the p-p collision count to its counters
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
@@ -124,3 +125,12 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot)
 hipError_t amc_launch_bin(amc_ctx *c);                 // count + scan + scatter over all n particles
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c);              // resolve_A -> validate -> resolve_B -> commit
+hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
+hipError_t amc_launch_commit(amc_ctx *c);
+hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack);
+// the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
+struct amc_resolve_ctl {
+    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
+    int rounds, ncand, active, ok, edges_done;
+    int nslots0;
+};

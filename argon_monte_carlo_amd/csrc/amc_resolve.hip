@@ -42,6 +42,9 @@ struct rs_args {
     amc_out O;
     long long n;
     int allpairs;
+    int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
+    int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
+    long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
     double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
     long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
 };
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         __syncthreads();
         RS_STAMP(3);
         const int nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        if (MODE == 0) {
+        if (MODE == 0 || (MODE == 1 && A.single_round)) {
             // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
             if (V.label != W.sl_label)
                 for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
@@ -785,9 +788,12 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         W.slot_of[p] = -1;
     }
     if (ok)
-        for (int e = gtid; e < nev; e += gstride)
+        for (int e = gtid; e < nev; e += gstride) {
+            const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];      // the particle whose free path completed
+            if (owner < A.lo || owner >= A.hi) continue;
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
                      W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
+        }
     for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // first-round overlay, if still set
     if (gtid == 0) {
         amc_dev_counters *cnt = A.O.cnt;
@@ -795,12 +801,58 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         cnt->n_clusters += (unsigned long long)ctl->nclusters;
         cnt->n_rounds += (unsigned long long)ctl->rounds;
         if (ok) {
-            cnt->n_pp += (unsigned long long)ctl->nhits;
-            cnt->n_fp_errors += (unsigned long long)ctl->nfp;
+            if (A.count_pp) {
+                cnt->n_pp += (unsigned long long)ctl->nhits;
+                cnt->n_fp_errors += (unsigned long long)ctl->nfp;
+            }
         } else {
             cnt->flags |= 4ULL;
         }
     }
+}
+
+// ---- multi-GPU helpers ------------------------------------------------------------------------------------------------------
+// candidate state table from the particle arrays (single GPU: the detect kernel gathers inline)
+__global__ __launch_bounds__(256) void k_gather_cst(rs_args A)
+{
+    const amc_resolve_ws &W = A.W;
+    const int ncand = min((int)A.O.cnt->cand_count, W.max_cand);
+    const size_t m = (size_t)W.max_cand;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ncand; k += gridDim.x * blockDim.x) {
+        const int pp[2] = {W.cand_j[k], W.cand_i[k]};
+        for (int w = 0; w < 2; w++) {
+            const int p = pp[w];
+            double *t = W.cst + (size_t)(11 * w) * m + k;
+            t[0 * m] = A.S.x[p]; t[1 * m] = A.S.y[p]; t[2 * m] = A.S.z[p];
+            t[3 * m] = A.S.vx[p]; t[4 * m] = A.S.vy[p]; t[5 * m] = A.S.vz[p];
+            t[6 * m] = A.S.d[p]; t[7 * m] = A.S.dx[p]; t[8 * m] = A.S.dy[p]; t[9 * m] = A.S.dz[p];
+            t[10 * m] = A.S.flag[p] ? 1.0 : 0.0;
+        }
+    }
+}
+
+// exchange table [11][n]: rows of the particles this rank owns, zero bits elsewhere (the all-reduce is a bitwise OR)
+__global__ __launch_bounds__(256) void k_pack_rows(amc_state S, const int *list, int n, long long lo, long long hi, double *table)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int p = list[u];
+    const bool own = p >= lo && p < hi;
+    const double v[11] = {S.x[p], S.y[p], S.z[p], S.vx[p], S.vy[p], S.vz[p], S.d[p], S.dx[p], S.dy[p], S.dz[p],
+                          S.flag[p] ? 1.0 : 0.0};
+    for (int e = 0; e < 11; e++) table[(size_t)e * n + u] = own ? v[e] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_unpack_rows(amc_state S, const int *list, int n, long long lo, long long hi, const double *table)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int p = list[u];
+    if (p >= lo && p < hi) return;          // the owner's copy is authoritative
+    S.x[p] = table[(size_t)0 * n + u]; S.y[p] = table[(size_t)1 * n + u]; S.z[p] = table[(size_t)2 * n + u];
+    S.vx[p] = table[(size_t)3 * n + u]; S.vy[p] = table[(size_t)4 * n + u]; S.vz[p] = table[(size_t)5 * n + u];
+    S.d[p] = table[(size_t)6 * n + u]; S.dx[p] = table[(size_t)7 * n + u]; S.dy[p] = table[(size_t)8 * n + u];
+    S.dz[p] = table[(size_t)9 * n + u];
+    S.flag[p] = table[(size_t)10 * n + u] != 0.0;
 }
 
 template <int GEOM>
@@ -816,12 +868,21 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
 }
 
-hipError_t amc_launch_resolve(amc_ctx *c)
+static rs_args rs_make_args(amc_ctx *c)
 {
     rs_args A;
     A.P = c->P; A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
     A.dbg = c->d_dbg;
+    A.single_round = 0;
+    A.count_pp = c->mg_count_pp ? 1 : 0;
+    A.lo = c->lo; A.hi = c->hi;
     A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;
+    return A;
+}
+
+hipError_t amc_launch_resolve(amc_ctx *c)
+{
+    const rs_args A = rs_make_args(c);
     amc_prof_begin(c, AMC_K_RESOLVE);
     switch (c->P.geometry) {
     case AMC_GEOM_CELL: rs_launch_all<AMC_GEOM_CELL>(c, A); break;
@@ -829,5 +890,45 @@ hipError_t amc_launch_resolve(amc_ctx *c)
     default: rs_launch_all<AMC_GEOM_PORE>(c, A); break;
     }
     amc_prof_end(c);
+    return hipGetLastError();
+}
+
+// multi-GPU: one round (first: claim + round 1, else one continuation round), then the wide validation
+template <int GEOM>
+static void rs_launch_round(amc_ctx *c, rs_args A, int first)
+{
+    if (first) {
+        hipLaunchKernelGGL(k_gather_cst, dim3(64), dim3(256), 0, c->stream, A);
+        hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    } else {
+        A.single_round = 1;
+        hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    }
+    hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
+}
+hipError_t amc_launch_resolve_round(amc_ctx *c, int first)
+{
+    const rs_args A = rs_make_args(c);
+    amc_prof_begin(c, AMC_K_RESOLVE);
+    switch (c->P.geometry) {
+    case AMC_GEOM_CUBE: rs_launch_round<AMC_GEOM_CUBE>(c, A, first); break;
+    default: rs_launch_round<AMC_GEOM_PORE>(c, A, first); break;
+    }
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+hipError_t amc_launch_commit(amc_ctx *c)
+{
+    const rs_args A = rs_make_args(c);
+    amc_prof_begin(c, AMC_K_RESOLVE);
+    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack)
+{
+    if (n <= 0) return hipSuccess;
+    if (unpack) hipLaunchKernelGGL(k_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, d_list, n, c->lo, c->hi, table);
+    else hipLaunchKernelGGL(k_pack_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, d_list, n, c->lo, c->hi, table);
     return hipGetLastError();
 }

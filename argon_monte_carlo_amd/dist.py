@@ -1,0 +1,181 @@
+"""Multi-GPU driver: one process per GPU, particles sharded by contiguous index range.
+
+Per step every rank advances only its shard (drift + walls + bounds), all-gathers the positions over RCCL/xGMI, detects
+the close pairs of the WHOLE system (same candidate set everywhere) and runs the identical ordered resolve on them, so
+cross-shard collisions and chains need no locking and no ownership logic inside the kernels.  The state (velocities,
+path accumulators, flag) of candidate particles owned by other ranks is exchanged on demand in a small table, by a
+integer SUM all-reduce of its int64 view (every entry is non-zero on exactly one rank, so the sum reproduces the
+owner's bits exactly, including -0.0 and NaN payloads; RCCL has no bitwise reductions).  If validation pulls further particles into a cluster, their rows are exchanged the same way
+before the next round.  The only data-path collectives are the position all-gather (24 B/particle/step) and those
+tables (a few hundred rows).
+
+``ShardedSimulation`` only needs an *engine* with the ``mg_*`` methods of ``engine.ShardEngine`` and a communicator;
+tests/test_dist_gloo.py drives it with a NumPy engine over gloo on CPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous index range [lo, hi) of ``rank``; equal shards when world divides n."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class TorchComm:
+    """torch.distributed collectives on tensors that alias engine memory.  backend "nccl" (= RCCL on ROCm) works on the
+    device tensors directly; "gloo" stages GPU tensors through the host (used for rehearsals on one GPU and on CPU)."""
+
+    def __init__(self, rank, world, group=None):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world, self.group = dist, rank, world, group
+        self.backend = dist.get_backend(group) if world > 1 else "none"
+
+    def _stage(self, t):
+        return t.is_cuda and self.backend != "nccl"
+
+    def allgather_inplace(self, full, n, world):
+        """full[lo:hi] of every rank -> full on every rank."""
+        if self.world == 1:
+            return
+        import torch
+        ranges = [shard_range(n, r, world) for r in range(world)]
+        lo, hi = ranges[self.rank]
+        equal = len({b - a for a, b in ranges}) == 1
+        if self._stage(full) or (not equal and self.backend != "nccl"):
+            parts = self.gather_shards(full[lo:hi].cpu(), ranges)
+            for (a, b), p in zip(ranges, parts):
+                if a != lo:
+                    full[a:b].copy_(p)
+        elif equal:
+            self.dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
+        else:
+            for r, (a, b) in enumerate(ranges):
+                self.dist.broadcast(full[a:b], src=r, group=self.group)
+
+    def gather_shards(self, mine, ranges):
+        """all-gather of (possibly unequal) host shards: padded to the longest one."""
+        import torch
+        m = max(b - a for a, b in ranges)
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        pad = torch.zeros(m, dtype=mine.dtype, device=dev)
+        pad[:mine.numel()] = mine
+        parts = [torch.empty(m, dtype=mine.dtype, device=dev) for _ in ranges]
+        self.dist.all_gather(parts, pad, group=self.group)
+        return [p[:b - a].cpu() for (a, b), p in zip(ranges, parts)]
+
+    def allreduce_bits(self, t):
+        if self.world == 1 or t.numel() == 0:
+            return
+        if self._stage(t):
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_sum_ints(self, values):
+        import torch
+        if self.world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.int64)
+        if self.backend == "nccl":
+            t = t.cuda()
+        self.dist.all_reduce(t, group=self.group)
+        return [int(v) for v in t.cpu().tolist()]
+
+    def allgather_rows(self, t_full, n, world):
+        """all-gather of an arbitrary per-particle tensor (used by download(), not on the hot path)."""
+        self.allgather_inplace(t_full, n, world)
+
+
+class ShardedSimulation:
+    SUM_KEYS = ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors")
+
+    def __init__(self, params, rank, world, backend="nccl", stream_ptr=None, engine=None, comm=None):
+        self.params, self.rank, self.world = params, int(rank), int(world)
+        self.n = int(params.n)
+        self.lo, self.hi = shard_range(self.n, rank, world)
+        if engine is None:
+            from .engine import ShardEngine
+            engine = ShardEngine(params, self.lo, self.hi)
+            if stream_ptr is not None:
+                engine.set_stream(stream_ptr)
+        self.engine = engine
+        self.comm = comm if comm is not None else TorchComm(rank, world)
+        self.max_rounds = 64
+
+    def upload(self, *arrays, **kw):
+        """Every rank uploads the full initial state (only its shard of the non-position arrays is ever used)."""
+        self.engine.upload(*arrays, **kw)
+
+    # ---- one step -------------------------------------------------------------------------------------------------------
+    def _exchange_state(self, particles):
+        """Rows of `particles` (ascending, identical on every rank) from their owners to everybody."""
+        if len(particles) == 0:
+            return
+        self.engine.mg_pack(particles)
+        self.comm.allreduce_bits(self.engine.exchange_tensor(len(particles)))
+        self.engine.mg_unpack(particles)
+
+    def timestep(self, dt, reduce_stats=True):
+        e = self.engine
+        e.mg_local(dt)
+        for t in e.position_tensors():
+            self.comm.allgather_inplace(t, self.n, self.world)
+        ncand = e.mg_detect()
+        rounds = 0
+        if ncand:
+            ci, cj = e.mg_candidates(ncand)
+            known = np.unique(np.concatenate([ci, cj]))              # canonical order: ascending particle index
+            self._exchange_state(known)
+            dirty, new = e.mg_resolve_round(True)
+            rounds = 1
+            while dirty:
+                if rounds >= self.max_rounds:
+                    raise RuntimeError("resolve did not converge")
+                self._exchange_state(new)
+                dirty, new = e.mg_resolve_round(False)
+                rounds += 1
+            e.mg_commit()
+        st = e.mg_finish()
+        st["n_rounds"] = rounds
+        if reduce_stats and self.world > 1:
+            tot = self.comm.allreduce_sum_ints([st[k] for k in self.SUM_KEYS])
+            st.update(dict(zip(self.SUM_KEYS, tot)))
+        return st
+
+    def run(self, dt, nsteps):
+        acc = None
+        for _ in range(int(nsteps)):
+            st = self.timestep(dt, reduce_stats=False)
+            acc = st if acc is None else {k: acc[k] + st[k] for k in st}
+        if acc is not None and self.world > 1:
+            tot = self.comm.allreduce_sum_ints([acc[k] for k in self.SUM_KEYS])
+            acc.update(dict(zip(self.SUM_KEYS, tot)))
+        return acc
+
+    # ---- results ---------------------------------------------------------------------------------------------------------
+    def download(self):
+        """Full state assembled from the owners (every rank returns the same arrays)."""
+        st = self.engine.download()
+        if self.world == 1:
+            return st
+        import torch
+        out = {}
+        ranges = [shard_range(self.n, r, self.world) for r in range(self.world)]
+        for k, v in st.items():
+            t = torch.from_numpy(np.ascontiguousarray(v))
+            parts = self.comm.gather_shards(t[self.lo:self.hi].contiguous(), ranges)
+            out[k] = torch.cat(parts).numpy()
+        return out
+
+    def histograms(self):
+        """Global free-path histograms = sum over ranks (every completed path is emitted by its particle's owner)."""
+        counts, tot = self.engine.histograms()
+        if self.world == 1:
+            return counts, tot
+        flat = self.comm.allreduce_sum_ints(list(counts.astype(np.int64).ravel()) + [int(tot)])
+        return np.array(flat[:-1], dtype=np.uint64).reshape(counts.shape), flat[-1]

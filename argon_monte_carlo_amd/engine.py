@@ -156,3 +156,73 @@ class Engine:
         cnt = np.zeros(8, dtype=np.int64)
         self._ck(self.lib.amc_kernel_times(self._ctx, _d(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
         return {AMC_K_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(8)}
+
+
+class ShardEngine(Engine):
+    """Engine + the multi-GPU entry points (include/argonmc.h, "multi-GPU"): the object dist.ShardedSimulation drives.
+    Positions and the exchange table are exposed as torch tensors that alias the library's device memory."""
+
+    def __init__(self, params, lo, hi):
+        super().__init__(params)
+        from ._abi import AmcDeviceView
+        self.lo, self.hi = int(lo), int(hi)
+        self._ck(self.lib.amc_set_shard(self._ctx, self.lo, self.hi))
+        self._view = AmcDeviceView()
+        self._ck(self.lib.amc_device_view_get(self._ctx, C.byref(self._view)))
+        self._i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+
+    @staticmethod
+    def _wrap(ptr, count, typestr):
+        import torch
+
+        class _Dev:
+            pass
+        d = _Dev()
+        d.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(d, device="cuda")
+
+    def position_tensors(self):
+        v = self._view
+        return [self._wrap(p, self.n, "<f8") for p in (v.x, v.y, v.z)]
+
+    def exchange_tensor(self, n_particles):
+        """int64 view of the state table rows in use: [11 * n_particles]."""
+        return self._wrap(self._view.xchg, 11 * int(n_particles), "<i8")
+
+    def mg_local(self, dt):
+        self._ck(self.lib.amc_mg_local(self._ctx, float(dt)))
+
+    def mg_detect(self):
+        n = C.c_int64(0)
+        self._ck(self.lib.amc_mg_detect(self._ctx, C.byref(n)))
+        return n.value
+
+    def mg_candidates(self, ncand):
+        ci = np.empty(max(1, ncand), dtype=np.int32)
+        cj = np.empty(max(1, ncand), dtype=np.int32)
+        got = C.c_size_t(0)
+        self._ck(self.lib.amc_mg_candidates(self._ctx, self._i32(ci), self._i32(cj), len(ci), C.byref(got)))
+        return ci[:got.value], cj[:got.value]
+
+    def mg_pack(self, particles):
+        p = np.ascontiguousarray(particles, dtype=np.int32)
+        self._ck(self.lib.amc_mg_pack_state(self._ctx, self._i32(p), len(p)))
+
+    def mg_unpack(self, particles):
+        p = np.ascontiguousarray(particles, dtype=np.int32)
+        self._ck(self.lib.amc_mg_unpack_state(self._ctx, self._i32(p), len(p)))
+
+    def mg_resolve_round(self, first):
+        dirty = C.c_int(0)
+        buf = np.empty(max(1024, self.n // 64), dtype=np.int32)
+        got = C.c_size_t(0)
+        self._ck(self.lib.amc_mg_resolve_round(self._ctx, int(first), C.byref(dirty), self._i32(buf), len(buf), C.byref(got)))
+        return bool(dirty.value), buf[:got.value].copy()
+
+    def mg_commit(self):
+        self._ck(self.lib.amc_mg_commit(self._ctx))
+
+    def mg_finish(self):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_mg_finish(self._ctx, C.byref(st)))
+        return st.as_dict()

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+The reference has no functions around its loop body; its "API" is a set of module-global ndarrays
+(``x_vals``, ``x_velocities``, ``dist_since_collision`` ... Pore:385-400), four completed-path lists (Pore:408-413),
+the per-step counter ``num_collisions_per_step`` (Pore:424) and ONE real function on the p-p path,
+``pairwise_particles_in_cell`` (Pore:160-255).  ``Simulation`` exposes exactly those names; ``timestep(dt)`` is one
+iteration of ``for i in range(num_timesteps)`` (Pore:416-557 / Cube:175-338) executed by libargonmc.so on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ic as IC
+from . import outputs as OUT
+from . import params as PR
+from .engine import Engine
+
+_NAMES = {"x_vals": "x", "y_vals": "y", "z_vals": "z", "x_velocities": "vx", "y_velocities": "vy",
+          "z_velocities": "vz", "dist_since_collision": "d", "dist_x_since_collision": "dx",
+          "dist_y_since_collision": "dy", "dist_z_since_collision": "dz", "full_path_traveled": "flag"}
+
+
+class Simulation:
+    """``kind``: "cube" (Open_Air_Cube_MC.py), "pore" (Open_Air_Pore_MC.py) — see params.py for the constants."""
+
+    def __init__(self, kind="pore", n=None, sigma=PR.SIGMA, device=0, keep_prior=False, tolerate_fp_errors=False,
+                 params=None, consts=None):
+        if params is None:
+            if kind == "cube":
+                params, consts = PR.cube_params(n=n, sigma=sigma, device=device) if n is None else \
+                    PR.cube_params_for_n(n, sigma=sigma, device=device)
+            elif kind == "pore":
+                params, consts = PR.pore_params(n=n, sigma=sigma, device=device)
+            else:
+                raise ValueError(kind)
+        if keep_prior:
+            params.reserved0 |= 1
+        if tolerate_fp_errors:
+            params.reserved1 |= 1
+        self.kind = kind
+        self.params, self.consts = params, consts
+        self.dt = consts["dt"]
+        self.engine = Engine(params)
+        self.completed_paths, self.completed_x_paths = [], []
+        self.completed_y_paths, self.completed_z_paths = [], []
+        self.num_collisions_per_step = 0          # Pore:424 (value of the last step)
+        self.total_cols = 0                        # Pore:556
+        self.steps_done = 0
+        self._cache = None
+
+    # ---- state, under the reference's names ----------------------------------------------------------------------
+    def set_state(self, x_vals, y_vals, z_vals, x_velocities, y_velocities, z_velocities, dist_since_collision=None,
+                  dist_x_since_collision=None, dist_y_since_collision=None, dist_z_since_collision=None,
+                  full_path_traveled=None):
+        self.engine.upload(x_vals, y_vals, z_vals, x_velocities, y_velocities, z_velocities, dist_since_collision,
+                           dist_x_since_collision, dist_y_since_collision, dist_z_since_collision, full_path_traveled)
+        self._cache = None
+
+    def init_synthetic(self, seed=None):
+        """Seeded synthetic initial conditions — the reference's own generators are host-side, one-off."""
+        gen = IC.cube_ic if self.kind == "cube" else IC.pore_ic
+        self.set_state(*gen(self.params, self.consts, seed if seed is not None else self.consts["seed"]))
+
+    def _state(self):
+        if self._cache is None:
+            self._cache = self.engine.download()
+        return self._cache
+
+    def __getattr__(self, name):
+        if name in _NAMES:
+            v = self._state()[_NAMES[name]]
+            return v.astype(bool) if name == "full_path_traveled" else v
+        if name in ("prior_x_vals", "prior_y_vals", "prior_z_vals"):
+            return self.engine.download_prior()["xyz".index(name[6])]
+        raise AttributeError(name)
+
+    # ---- the loop body -----------------------------------------------------------------------------------------------
+    def timestep(self, dt=None, collect_paths=True):
+        """One iteration of the reference's time loop.  Returns the step's counters."""
+        st = self.engine.timestep(self.dt if dt is None else dt)
+        self._cache = None
+        self.num_collisions_per_step = st["n_pp"] + st["n_wall"]
+        self.total_cols += self.num_collisions_per_step
+        self.steps_done += 1
+        if collect_paths:
+            self._collect()
+        return st
+
+    def run(self, nsteps, dt=None):
+        """``nsteps`` iterations without host synchronisation in between (histograms accumulate on the device)."""
+        st = self.engine.run(self.dt if dt is None else dt, nsteps)
+        self._cache = None
+        self.num_collisions_per_step = None
+        self.total_cols += st["n_pp"] + st["n_wall"]
+        self.steps_done += nsteps
+        return st
+
+    def _collect(self):
+        rec = self.engine.drain_paths(sort=True)
+        if len(rec):
+            self.completed_paths.extend(rec["total"].tolist())
+            self.completed_x_paths.extend(rec["px"].tolist())
+            self.completed_y_paths.extend(rec["py"].tolist())
+            self.completed_z_paths.extend(rec["pz"].tolist())
+
+    # ---- end of run (Pore:559-630) -------------------------------------------------------------------------------------
+    def histograms(self):
+        """(densities dict, bin edges) from the histograms accumulated on the device."""
+        counts, _ = self.engine.histograms()
+        dens = {}
+        edges = None
+        for row, key in enumerate(["total", "x", "y", "z"]):
+            dens[key], edges = OUT.density_from_counts(counts[row], self.params.hist_lo, self.params.hist_hi)
+        return dens, edges
+
+    def write_outputs(self, directory="."):
+        dens, edges = self.histograms()
+        OUT.write_histograms(directory, dens, edges)
+
+    def close(self):
+        self.engine.close()
+
+
+# ---- the one real function boundary of the reference: pairwise_particles_in_cell (Pore:160-255) ---------------------
+num_collisions_per_step = None       # injected by init_globals(counter), exactly like Pore:350-352
+_cell_engines = {}
+
+
+def init_globals(counter):
+    global num_collisions_per_step
+    num_collisions_per_step = counter
+
+
+def pairwise_particles_in_cell(completed_paths, completed_x_paths, completed_y_paths, completed_z_paths, in_cell,
+                               continue_path, continue_x_path, continue_y_path, continue_z_path, has_collided,
+                               x_positions_in_cell, y_positions_in_cell, z_positions_in_cell, x_velocities_in_cell,
+                               y_velocities_in_cell, z_velocities_in_cell, sigma=PR.SIGMA, device=0):
+    """Same signature, argument meaning, return tuple and side effects as the reference function: the per-cell arrays
+    are updated as the sequential i>j loop would, completed free paths are appended to the four lists in loop order,
+    and the shared counter gets the number of collisions (Pore:244-251).  The pair loop runs on the GPU."""
+    if num_collisions_per_step is None:
+        raise NameError("name 'num_collisions_per_step' is not defined")     # what the reference raises (Pore:244)
+    n = int(np.sum(in_cell))
+    cap = 1
+    while cap < max(n, 2):
+        cap <<= 1
+    key = (cap, float(sigma), device)
+    eng = _cell_engines.get(key)
+    if eng is None:
+        p, _ = PR.cell_params(sigma=sigma, n=cap, device=device)
+        eng = _cell_engines[key] = Engine(p)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64).copy() for a in
+            (continue_path, continue_x_path, continue_y_path, continue_z_path)]
+    flag = np.ascontiguousarray(np.asarray(has_collided).astype(np.uint8))
+    pos = [np.ascontiguousarray(a, dtype=np.float64).copy() for a in
+           (x_positions_in_cell, y_positions_in_cell, z_positions_in_cell, x_velocities_in_cell,
+            y_velocities_in_cell, z_velocities_in_cell)]
+    paths, ncoll = eng.pairwise_cell(arrs[0], arrs[1], arrs[2], arrs[3], flag, *pos)
+    with num_collisions_per_step.get_lock():
+        num_collisions_per_step.value += ncoll
+    completed_paths.extend(paths[:, 0].tolist())
+    completed_x_paths.extend(paths[:, 1].tolist())
+    completed_y_paths.extend(paths[:, 2].tolist())
+    completed_z_paths.extend(paths[:, 3].tolist())
+    return (in_cell, arrs[0], arrs[1], arrs[2], arrs[3], flag.astype(bool), pos[0], pos[1], pos[2], pos[3], pos[4],
+            pos[5])

@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--workload", default="cube_1e5", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the particle count per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -92,10 +94,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from argon_monte_carlo_amd.engine import Engine
 
@@ -117,7 +124,7 @@ def main():
         from argon_monte_carlo_amd.dist import ShardedSimulation
         n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
-        sim = ShardedSimulation(p, rank, world, backend="nccl", stream_ptr=stream_ptr)
+        sim = ShardedSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
         sim.upload(*init)
         step = lambda k: sim.run(c["dt"], k)          # noqa: E731
         parallelism = f"index-range shards x{world}, per-step all-gather of positions (RCCL)"
@@ -136,7 +143,7 @@ def main():
     sync()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device="cuda", dtype=torch.float64)
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 

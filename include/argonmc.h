@@ -207,23 +207,40 @@ int amc_paths_pending(amc_ctx *ctx, size_t *n);
 int amc_histograms(amc_ctx *ctx, uint64_t *counts, uint64_t *n_paths_total);
 int amc_reset_outputs(amc_ctx *ctx);
 
-/* ---- multi-GPU (one process per GPU; particles sharded by index range, Survey 8e) ------------------------ */
-/* This rank owns particles [lo, hi).  Default [0, n). */
+/* ---- multi-GPU (one process per GPU; particles sharded by index range) ------------------------------
+ * Every rank allocates all n particles but advances only its shard [lo, hi).  Per step (argon_monte_carlo_amd/dist.py):
+ *   amc_mg_local            drift + walls + bounds on [lo,hi)                       (Pore:426-512 on the shard)
+ *   <all-gather x,y,z>      RCCL, in place on the pointers of amc_device_view
+ *   amc_mg_detect           bin ALL n particles + close-pair detection -> the same candidate SET on every rank
+ *   amc_mg_candidates       the pairs, for the host to build the canonical (sorted) list of particles to exchange
+ *   amc_mg_pack_state       rows of the owned particles of that list into the exchange table (zeros elsewhere)
+ *   <all-reduce SUM/int64>  integer sum over the int64 view of the table (one non-zero contributor per entry): exact,
+ *                           keeps -0.0 and NaN payloads
+ *   amc_mg_unpack_state     table rows -> local arrays of the non-owned particles of the list
+ *   amc_mg_resolve_round    one round of the ordered resolve + wide validation; returns whether clusters merged and
+ *                           which not-yet-exchanged particles were pulled in (their state is exchanged the same way
+ *                           before the next round, so every rank emulates every cluster on identical inputs)
+ *   amc_mg_commit           results -> particle arrays (every rank applies all of them; owners stay authoritative)
+ *   amc_mg_finish           bounds check after the sweep on [lo,hi), step counter, per-step counters
+ * No data-path collective other than the position all-gather and the small state tables. */
 int amc_set_shard(amc_ctx *ctx, int64_t lo, int64_t hi);
-/* Raw device pointers for the collectives the host runs with torch.distributed (RCCL): positions are float64[n]
- * each (all-gathered per step); xchg is the candidate-exchange buffer (amc_mg_* below). */
 typedef struct amc_device_view {
-    void *x, *y, *z;              /* float64[n]                                                         */
-    void *xchg_send;              /* this rank's packed candidate records                              */
-    void *xchg_recv;              /* world_size * xchg_stride bytes                                    */
-    int64_t xchg_stride;          /* bytes per rank slot                                               */
-    int64_t xchg_record_bytes;
+    void *x, *y, *z;              /* float64[n] each: the position arrays themselves (all-gathered in place)      */
+    void *xchg;                   /* exchange table, float64[11][xchg_capacity] (row-major), also viewed as int64 */
+    int64_t xchg_capacity;        /* particles per exchange                                                      */
+    int64_t n, lo, hi;
 } amc_device_view;
-int amc_device_view_get(amc_ctx *ctx, int world_size, amc_device_view *out);
-int amc_mg_local(amc_ctx *ctx, double dt);                    /* drift + walls + bounds on [lo,hi)      */
-int amc_mg_detect_pack(amc_ctx *ctx, int64_t *n_records);     /* after the position all-gather          */
-int amc_mg_resolve(amc_ctx *ctx, int world_size, const int64_t *n_records_per_rank, amc_step_stats *out);
-int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);         /* bounds check after the sweep on [lo,hi) */
+int amc_device_view_get(amc_ctx *ctx, amc_device_view *out);
+int amc_mg_local(amc_ctx *ctx, double dt);
+int amc_mg_detect(amc_ctx *ctx, int64_t *n_candidates);
+int amc_mg_candidates(amc_ctx *ctx, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n);
+int amc_mg_pack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
+int amc_mg_unpack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
+/* first != 0: start the sweep (claim slots, round 1); else continue with the next round.  *dirty = clusters merged
+ * (another round is needed); new_members receives the particles pulled in by validation (ascending). */
+int amc_mg_resolve_round(amc_ctx *ctx, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new);
+int amc_mg_commit(amc_ctx *ctx);
+int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);
 
 /* ---- measurement ----------------------------------------------------------------------------------------- */
 /* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */

@@ -1,0 +1,79 @@
+"""GPU (-m gpu): the sharded path with 2 ranks on ONE MI355X (gloo, collectives staged through the host — RCCL refuses
+two ranks on one device) must equal the single-context engine bit for bit: state, counters and histograms."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz", "flag"]
+
+
+def _case(kind, n):
+    from argon_monte_carlo_amd import ic as IC, params as PR
+    if kind == "cube":
+        p, c = PR.cube_params_for_n(n)
+        init = IC.cube_ic(p, c, seed=11)
+    else:
+        p, c = PR.pore_params(n=n)
+        init = IC.pore_ic(p, c, seed=11)
+    p.detect_mode = 1
+    return p, c, init
+
+
+def _worker(rank, world, port, kind, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from argon_monte_carlo_amd.dist import ShardedSimulation
+        p, c, init = _case(kind, n)
+        sim = ShardedSimulation(p, rank, world, backend="gloo")
+        sim.upload(*init)
+        tot = sim.run(c["dt"], steps)
+        full = sim.download()
+        counts, npaths = sim.histograms()
+        if rank == 0:
+            q.put((full, tot, counts, npaths))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("kind,n,steps", [("cube", 30000, 8), ("pore", 60000, 6)])
+def test_two_ranks_one_gpu_equal_single_engine(kind, n, steps):
+    from argon_monte_carlo_amd.engine import Engine
+    p, c, init = _case(kind, n)
+    eng = Engine(p)
+    eng.upload(*init)
+    ref_tot = eng.run(c["dt"], steps)
+    ref = eng.download()
+    ref_counts, ref_npaths = eng.histograms()
+    eng.close()
+    assert ref_tot["n_pp"] > 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, n, steps, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    full, tot, counts, npaths = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for k in KEYS:
+        assert np.array_equal(full[k], ref[k]), (kind, k, np.flatnonzero(full[k] != ref[k])[:5])
+    for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+        assert tot[k] == ref_tot[k], (k, tot, ref_tot)
+    assert npaths == ref_npaths and np.array_equal(counts, ref_counts)

@@ -1,0 +1,84 @@
+"""CPU-only checks of the host layer: output writers against the files the reference itself wrote (tests/golden),
+the C-ABI library's exports, parameter evaluation, and the no-fallback rule."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from argon_monte_carlo_amd import _lib, outputs as OUT, params as PR
+from argon_monte_carlo_amd._abi import AmcParams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "argonmc.h")).read()
+    declared = set(re.findall(r"^(?:int|void|const char \*)\s*\*?\s*(amc_[a-z_]+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 30
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.amc_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from argon_monte_carlo_amd.engine import Engine
+    with pytest.raises(_lib.ArgonMCError) as ei:
+        Engine(PR.cube_params(n=100)[0])
+    assert ei.value.code == -2
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "argon_monte_carlo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.lower().replace("# oracle", "").replace("the cpu oracle has both", "") or \
+                    fn in ("amc_device.h",), fn
+
+
+def test_params_match_reference_constants(golden_dir):
+    G = np.load(os.path.join(golden_dir, "consts.npz"))
+    p, c = PR.pore_params()
+    for k in ["dx", "dz", "dt", "argon_radius", "collision_range", "a_shape", "num_molecules", "lambda_mfp", "tau",
+              "open_air_particles", "cold_pore_particles", "hot_pore_particles", "gap_particles", "remaining_particles"]:
+        assert float(G["pore_" + k]) == float(c[k]), k
+    assert p.z_gap_top == float(G["pore_z_gap_top_expr"]) and p.z_gap_bottom == float(G["pore_z_gap_bottom_expr"])
+    assert p.R_oa_sq == float(G["pore_R_oa_sq"]) and p.R_g_sq == float(G["pore_R_g_sq"]) and p.R_p_sq == float(G["pore_R_p_sq"])
+    assert p.R_oa_c == float(G["pore_open_air_collision_radius"]) and p.R_g_c == float(G["pore_gap_collision_radius"])
+    assert p.R_p_c == float(G["pore_pore_collision_radius"])
+    pt, ct = PR.pore_params(energised=True)
+    for k in ["dt", "a_shape", "num_molecules", "lambda_mfp"]:
+        assert float(G["temp_" + k]) == float(ct[k]), k
+    assert pt.R_g_c_sq == float(G["temp_R_g_c_sq"]) and pt.R_p_c_sq == float(G["temp_R_p_c_sq"])
+    assert pt.z_gap_top == float(G["temp_gap_top_height"]) and pt.z_gap_bottom == float(G["temp_gap_bottom_height"])
+    pc, cc = PR.cube_params()
+    for k in ["dt", "num_molecules", "a_shape", "tau"]:
+        assert float(G["cube_" + k]) == float(cc[k]), k
+    assert pc.overlap_x == float(G["cube_collision_x_overlap"]) and pc.dx == float(G["cube_dx"])
+    assert C.sizeof(AmcParams) == pc.struct_size
+
+
+def test_histogram_files_byte_identical_to_the_reference(golden_dir, tmp_path):
+    """The 8 text files the (patched) reference run wrote are reproduced from its completed-path lists."""
+    G = np.load(os.path.join(golden_dir, "step_pore_a.npz"))
+    dens = {}
+    edges = None
+    for key, name in (("total", "completed_paths"), ("x", "completed_x_paths"), ("y", "completed_y_paths"),
+                      ("z", "completed_z_paths")):
+        dens[key], edges = OUT.density_from_paths(G[name])
+        # the device path produces integer counts; density from counts must be the same floats
+        counts, _ = np.histogram(G[name], bins=200, range=(0, 10**-6))
+        d2, e2 = OUT.density_from_counts(counts)
+        assert np.array_equal(d2, dens[key]) and np.array_equal(e2, edges)
+    OUT.write_histograms(str(tmp_path), dens, edges)
+    for _, fx, fy in OUT.HIST_FILES:
+        for fn in (fx, fy):
+            assert open(tmp_path / fn, "rb").read() == bytes(G["file_" + fn]), fn
