@@ -39,6 +39,8 @@ SIGNATURES = {
     "amc_stage_sweep": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_pairwise_cell": (C.c_int, [_ctx, C.c_int64] + [_dp] * 4 + [_u8p] + [_dp] * 6 + [_dp, C.c_size_t,
                                                                                        C.POINTER(C.c_size_t), _i64p]),
+    "amc_temp_begin": (C.c_int, [_ctx, C.c_double]),
+    "amc_temp_end": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),
     "amc_drain_paths": (C.c_int, [_ctx, C.POINTER(AmcPathRecord), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -165,7 +165,8 @@ void amc_destroy(amc_ctx *c)
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
                     c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
-                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl};
+                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
+                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -203,6 +204,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(c->k_ms, 0, sizeof c->k_ms);
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
+    c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
+    c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
@@ -647,8 +650,109 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
 }
 
 // ---- not yet available in this build ----------------------------------------------------------------------------------
-int amc_wall_hits(amc_ctx *c, int, int32_t *, double *, double *, size_t, size_t *) { return amc_fail(c, AMC_ERR_INVALID, "energised walls: not implemented yet"); }
-int amc_wall_apply(amc_ctx *c, int, const double *, const double *, size_t, double *, double *) { return amc_fail(c, AMC_ERR_INVALID, "energised walls: not implemented yet"); }
+// ---- energised walls (Temp) ---------------------------------------------------------------------------------------------
+static int temp_ensure(amc_ctx *c)
+{
+    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "energised-wall calls need AMC_GEOM_PORE_ENERGISED");
+    if (c->T.idx) return AMC_OK;
+    amc_temp_ws &T = c->T;
+    T.cap = (int)std::min<int64_t>(std::max<int64_t>(4096, c->n / 8 + 1024), 0x3fffffff);
+    const size_t cap = (size_t)T.cap;
+    AMC_HIP(c, dalloc(&T.idx, cap)); AMC_HIP(c, dalloc(&T.count, 1)); AMC_HIP(c, dalloc(&T.t, cap));
+    AMC_HIP(c, dalloc(&T.contact, 3 * cap)); AMC_HIP(c, dalloc(&T.normal, 3 * cap)); AMC_HIP(c, dalloc(&T.dir, 3 * cap));
+    AMC_HIP(c, dalloc(&T.Es, cap)); AMC_HIP(c, dalloc(&T.dpz, cap)); AMC_HIP(c, dalloc(&T.dE, cap)); AMC_HIP(c, dalloc(&T.ok, cap));
+    T.last_case = -1; T.last_n = 0;
+    return AMC_OK;
+}
+
+int amc_temp_begin(amc_ctx *c, double dt)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_ensure(c);
+    if (rc) return rc;
+    c->keep_prior = true;       // the energised masks read prior_*_vals (Temp:708-750)
+    AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
+    return AMC_OK;
+}
+
+int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, size_t cap, size_t *n)
+{
+    if (!c || !n || case_id < 3 || case_id > 9) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_ensure(c);
+    if (rc) return rc;
+    amc_temp_ws &T = c->T;
+    AMC_HIP(c, amc_launch_temp_hits(c, case_id));
+    int cnt = 0;
+    AMC_HIP(c, hipMemcpyAsync(&cnt, T.count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    if (cnt > T.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits exceed the record capacity %d", cnt, T.cap);
+    if ((size_t)cnt > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits, caller buffer holds %zu", cnt, cap);
+    T.last_case = case_id; T.last_n = cnt;
+    T.perm.resize((size_t)cnt);
+    *n = (size_t)cnt;
+    if (cnt == 0) return AMC_OK;
+    std::vector<int> hidx((size_t)cnt);
+    std::vector<double> hnorm(3 * (size_t)cnt), hcontact(3 * (size_t)cnt);
+    AMC_HIP(c, hipMemcpy(hidx.data(), T.idx, sizeof(int) * cnt, hipMemcpyDeviceToHost));
+    AMC_HIP(c, hipMemcpy(hnorm.data(), T.normal, sizeof(double) * 3 * cnt, hipMemcpyDeviceToHost));
+    AMC_HIP(c, hipMemcpy(hcontact.data(), T.contact, sizeof(double) * 3 * cnt, hipMemcpyDeviceToHost));
+    for (int k = 0; k < cnt; k++) T.perm[k] = k;
+    std::sort(T.perm.begin(), T.perm.end(), [&](int a, int b) { return hidx[a] < hidx[b]; });   // ascending particle index
+    for (int s = 0; s < cnt; s++) {
+        const int k = T.perm[s];
+        if (idx) idx[s] = hidx[k];
+        if (normal_xyz) { normal_xyz[3 * s] = hnorm[3 * k]; normal_xyz[3 * s + 1] = hnorm[3 * k + 1]; normal_xyz[3 * s + 2] = hnorm[3 * k + 2]; }
+        if (contact_z) contact_z[s] = hcontact[3 * k + 2];
+    }
+    return AMC_OK;
+}
+
+int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double *surface_energy, size_t n, double *dpz, double *dE)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_temp_ws &T = c->T;
+    if (!T.idx || T.last_case != case_id || (size_t)T.last_n != n)
+        return amc_fail(c, AMC_ERR_STATE, "amc_wall_apply(case %d, n=%zu) does not match the pending amc_wall_hits(case %d, n=%d)", case_id, n, T.last_case, T.last_n);
+    T.last_case = -1;
+    if (n == 0) return AMC_OK;
+    if (!dir_xyz || !surface_energy) return AMC_ERR_INVALID;
+    // caller order (ascending particle index) -> record order
+    std::vector<double> hdir(3 * n), hEs(n);
+    for (size_t s = 0; s < n; s++) {
+        const int k = T.perm[s];
+        hdir[3 * k] = dir_xyz[3 * s]; hdir[3 * k + 1] = dir_xyz[3 * s + 1]; hdir[3 * k + 2] = dir_xyz[3 * s + 2];
+        hEs[k] = surface_energy[s];
+    }
+    AMC_HIP(c, hipMemcpyAsync(T.dir, hdir.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    AMC_HIP(c, hipMemcpyAsync(T.Es, hEs.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n));
+    std::vector<double> hp(n), he(n);
+    AMC_HIP(c, hipMemcpyAsync(hp.data(), T.dpz, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipMemcpyAsync(he.data(), T.dE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t s = 0; s < n; s++) {
+        if (dpz) dpz[s] = hp[T.perm[s]];
+        if (dE) dE[s] = he[T.perm[s]];
+    }
+    return AMC_OK;
+}
+
+int amc_temp_end(amc_ctx *c, amc_step_stats *out)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "amc_temp_end needs AMC_GEOM_PORE_ENERGISED");
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));        // Temp:804
+    int rc = enqueue_sweep(c);                                      // Temp:813-842
+    if (rc) return rc;
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));        // Temp:844
+    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    return finish_stats(c, out);
+}
+
 int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
 {
     if (!c || lo < 0 || hi < lo || hi > c->n) return AMC_ERR_INVALID;

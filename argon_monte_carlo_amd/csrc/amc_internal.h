@@ -64,6 +64,16 @@ struct amc_resolve_ws {
     double *cst;              // [22][max_cand] state of both particles of every candidate, gathered by detect
 };
 
+// energised-wall hand-over buffers (amc_energised.hip)
+struct amc_temp_ws {
+    int *idx, *count;
+    double *t, *contact, *normal, *dir, *Es, *dpz, *dE;
+    unsigned char *ok;
+    int cap;
+    int last_case, last_n;       // the pending amc_wall_hits
+    std::vector<int> perm;       // sorted position -> record slot of the pending hits
+};
+
 struct amc_ctx {
     amc_params P;
     int device;
@@ -80,6 +90,7 @@ struct amc_ctx {
     int *scan_tmp;
     int scan_blocks;
     amc_resolve_ws W;
+    amc_temp_ws T;
     bool allpairs;
     // outputs
     amc_out out;
@@ -127,6 +138,8 @@ hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, f
 hipError_t amc_launch_resolve(amc_ctx *c);              // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
 hipError_t amc_launch_commit(amc_ctx *c);
+hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
+hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
 hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack);
 // the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
 struct amc_resolve_ctl {

@@ -831,7 +831,7 @@ __global__ __launch_bounds__(256) void k_gather_cst(rs_args A)
     }
 }
 
-// exchange table [11][n]: rows of the particles this rank owns, zero bits elsewhere (the all-reduce is a bitwise OR)
+// exchange table [11][n]: rows of the particles this rank owns, zero bits elsewhere (the all-reduce is an integer SUM of the int64 view: exact)
 __global__ __launch_bounds__(256) void k_pack_rows(amc_state S, const int *list, int n, long long lo, long long hi, double *table)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;

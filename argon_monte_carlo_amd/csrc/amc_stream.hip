@@ -78,6 +78,14 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
                 (((q.z < P.z_cold) && (q.z > zt)) || ((q.z < zb) && (q.z > P.h_oa)))) { // CASE 6, Pore:482
                 if (amc_side_wall(q, P.R_p_c, true, O, 9, ip)) nerr++; else nwall++;
             }
+        } else if (GEOM == AMC_GEOM_PORE_ENERGISED) {
+            // Temp:693-703 — cases 1 and 2 are specular WITHOUT free-path bookkeeping or counter (Temp:311-347);
+            // the energised cases 3-6 follow in amc_energised.hip around the host's random draws
+            if (sqrt(q.x * q.x + q.y * q.y) > P.R_oa) {                                  // CASE 1, Temp:693
+                if (amc_side_wall(q, P.R_oa_c, false, O, 1, (int)p)) nerr++;
+            }
+            if (q.z < 0) { const double t_ = (q.z - 0.0) / q.vz; q.vz = -q.vz; q.z = 0.0 + t_ * q.vz; }       // Temp:699
+            if (q.z > P.H) { const double t_ = (q.z - P.H) / q.vz; q.vz = -q.vz; q.z = P.H + t_ * q.vz; }       // Temp:702
         }
     }
 

@@ -226,3 +226,46 @@ class ShardEngine(Engine):
         st = AmcStepStats()
         self._ck(self.lib.amc_mg_finish(self._ctx, C.byref(st)))
         return st.as_dict()
+
+
+class EnergisedEngine(Engine):
+    """Engine + the energised-wall hand-over (Temp:705-758): ``wall_hits`` / ``wall_apply`` are the hooks that
+    ``energised.drive_energised_cases`` drives once per case."""
+
+    def temp_begin(self, dt):
+        self._ck(self.lib.amc_temp_begin(self._ctx, float(dt)))
+
+    def wall_hits(self, case):
+        cap = max(4096, self.n // 8 + 1024)
+        idx = np.empty(cap, dtype=np.int32)
+        normal = np.empty((cap, 3))
+        cz = np.empty(cap)
+        n = C.c_size_t(0)
+        self._ck(self.lib.amc_wall_hits(self._ctx, int(case), idx.ctypes.data_as(C.POINTER(C.c_int32)), _d(normal), _d(cz),
+                                        cap, C.byref(n)))
+        k = n.value
+        nm = normal[:k].copy()
+        ok = np.any(nm != 0.0, axis=1)          # a zero normal marks a failed contact solve (Temp:472-474)
+        return idx[:k].copy(), nm, cz[:k].copy(), ok
+
+    def wall_apply(self, case, dirs, Es):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        Es = np.ascontiguousarray(Es, dtype=np.float64)
+        n = len(Es)
+        dpz = np.zeros(max(1, n))
+        dE = np.zeros(max(1, n))
+        self._ck(self.lib.amc_wall_apply(self._ctx, int(case), _d(dirs), _d(Es), n, _d(dpz), _d(dE)))
+        return dpz[:n], dE[:n]
+
+    def temp_end(self):
+        st = AmcStepStats()
+        self._ck(self.lib.amc_temp_end(self._ctx, C.byref(st)))
+        return st.as_dict()
+
+    def temp_timestep(self, dt, sampler, energies):
+        """One iteration of Temperature_Pore_MC.py's loop (Temp:662-853)."""
+        from .energised import drive_energised_cases
+        self.temp_begin(dt)
+        res = drive_energised_cases(self, sampler, energies)
+        st = self.temp_end()
+        return (st,) + res

@@ -121,6 +121,69 @@ class Simulation:
         self.engine.close()
 
 
+class TemperatureSimulation(Simulation):
+    """Temperature_Pore_MC.py: energised walls, per-step z-momentum / energy transfer and momentum_energy.csv
+    (Temp:634-638, 756-758, 929-933).  The random directions come from ``np.random`` / ``random`` (module-level streams
+    by default, as in the reference) in strict particle order; see energised.py."""
+
+    def __init__(self, n=None, sigma=PR.SIGMA, device=0, np_rng=None, py_rng=None, params=None, consts=None):
+        from .energised import DirectionSampler, SurfaceEnergies
+        from .engine import EnergisedEngine
+        if params is None:
+            params, consts = PR.pore_params(n=n, sigma=sigma, energised=True, device=device)
+        params.reserved0 |= 1
+        self.kind = "temp"
+        self.params, self.consts = params, consts
+        self.dt = consts["dt"]
+        self.energies = SurfaceEnergies(consts)
+        params.E_cold, params.E_hot = self.energies.cold, self.energies.hot
+        self.engine = EnergisedEngine(params)
+        self.sampler = DirectionSampler(np_rng, py_rng)
+        self.completed_paths, self.completed_x_paths = [], []
+        self.completed_y_paths, self.completed_z_paths = [], []
+        self.num_collisions_per_step = 0
+        self.total_cols = 0
+        self.total_errs = 0
+        self.steps_done = 0
+        self._cache = None
+        self.momentum_z_change_per_step = []          # Temp:634
+        self.energy_transfer_hot_per_step = []        # Temp:637
+        self.energy_transfer_cold_per_step = []       # Temp:638
+        self._zero_flags = []
+
+    def init_synthetic(self, seed=None):
+        self.set_state(*IC.pore_ic(self.params, self.consts, seed if seed is not None else self.consts["seed"]))
+
+    def timestep(self, dt=None, collect_paths=True):
+        st, mom, cold, hot, had_m, had_c, had_h = self.engine.temp_timestep(self.dt if dt is None else dt, self.sampler,
+                                                                            self.energies)
+        self._cache = None
+        self.momentum_z_change_per_step.append(mom)
+        self.energy_transfer_cold_per_step.append(cold)
+        self.energy_transfer_hot_per_step.append(hot)
+        self._zero_flags.append((not had_m, not had_c, not had_h))
+        self.num_collisions_per_step = st["n_pp"] + st["n_wall"]
+        self.total_cols += self.num_collisions_per_step
+        self.total_errs += st["n_fp_errors"]
+        self.steps_done += 1
+        if collect_paths:
+            self._collect()
+        return st
+
+    def run(self, nsteps, dt=None):
+        for _ in range(int(nsteps)):
+            self.timestep(dt, collect_paths=False)
+
+    def write_outputs(self, directory="."):
+        import os
+        from .energised import format_mpf
+        super().write_outputs(directory)
+        m = [format_mpf(v, z[0]) for v, z in zip(self.momentum_z_change_per_step, self._zero_flags)]
+        c = [format_mpf(v, z[1]) for v, z in zip(self.energy_transfer_cold_per_step, self._zero_flags)]
+        h = [format_mpf(v, z[2]) for v, z in zip(self.energy_transfer_hot_per_step, self._zero_flags)]
+        OUT.write_momentum_energy_csv(os.path.join(directory, "momentum_energy.csv"), m, c, h)
+
+
 # ---- the one real function boundary of the reference: pairwise_particles_in_cell (Pore:160-255) ---------------------
 num_collisions_per_step = None       # injected by init_globals(counter), exactly like Pore:350-352
 _cell_engines = {}

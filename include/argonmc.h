@@ -63,7 +63,7 @@ typedef struct amc_params {
 
     /* reference cell grid of the p-p sweep (Cube:30-38,233-237; Pore:41-46,527-529) */
     int32_t nx, ny, nz;           /* num_{x,y,z}_subdivions                                            */
-    int32_t reserved0;
+    int32_t reserved0;            /* flags: bit0 = keep prior_{x,y,z}_vals (amc_download_prior)            */
     double dx, dy, dz;
     double overlap_x, overlap_y, overlap_z;   /* Cube: d/10 ; Pore/Temp: collision_range                */
 
@@ -99,7 +99,8 @@ typedef struct amc_params {
 
     /* free-path histogram (Pore:93,575): nbins equal bins on [hist_lo, hist_hi] */
     int32_t hist_bins;
-    int32_t reserved1;
+    int32_t reserved1;            /* flags: bit0 = count-and-continue on a failed wall/contact solve (Temp:340-342)
+                                     instead of reporting AMC_ERR_FP (what Pore:336-338 / np.seterr amount to)   */
     double hist_lo, hist_hi;
 
     /* engine knobs (not physics) */
@@ -188,15 +189,24 @@ int amc_pairwise_cell(amc_ctx *ctx, int64_t n_cell, double *continue_path, doubl
                       size_t *n_paths, int64_t *n_collisions);
 
 /* ---- energised walls: host-RNG handshake (Temp:132-141 consumes two Mersenne-Twister streams in particle order,
- * Temp:147-152 calls mpmath.quad per gap hit — both stay on the host) ------------------------------------------ */
-/* amc_wall_hits: evaluates the mask of energised case `case_id` (3..9 in evaluation order, Temp:708-751) on the
- * current state, returns hit particle indices in ascending order, their inward unit normals and contact z. */
+ * Temp:147-152 calls mpmath.quad per gap hit — both stay on the host; argon_monte_carlo_amd/energised.py) -----------
+ * One step of Temperature_Pore_MC.py (Temp:662-853) is
+ *     amc_temp_begin(dt);  for case in 3..9: amc_wall_hits(case) -> host draws -> amc_wall_apply(case);  amc_temp_end()
+ * case ids in the reference's evaluation order (Temp:708-751): 3 case-3 cold plane, 4 case-3 hot plane, 5 case-4 gap
+ * side wall, 6 case-5 bottom plane, 7 case-5 top plane, 8 case-6 hot side wall, 9 case-6 cold side wall. */
+/* drift (Temp:672-683) + specular cases 1-2 (Temp:693-703) */
+int amc_temp_begin(amc_ctx *ctx, double dt);
+/* Evaluates the mask of energised case `case_id` on the current state; returns the hit particles in ASCENDING index
+ * with the inward unit normal handed to random_inbounds_direction (Temp:375,444; (0,0,0) marks a hit whose contact
+ * solve fails, Temp:472-474: no draw is consumed for it) and the contact z (surface_energy_gap argument, Temp:519). */
 int amc_wall_hits(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, size_t cap,
                   size_t *n);
-/* amc_wall_apply: applies re-emission for those hits: unit direction (3 per hit) and surface energy per hit;
- * returns the summed z-momentum and energy change exactly as Temp:384-389 accumulates them (in hit order). */
+/* Re-emission of those hits: unit direction (3 per hit) and surface energy per hit, in the same order; writes the
+ * per-hit z-momentum and energy changes (Temp:384-389), which the caller sums left to right like the reference. */
 int amc_wall_apply(amc_ctx *ctx, int case_id, const double *dir_xyz, const double *surface_energy, size_t n,
-                   double *dpz_sum, double *dE_sum);
+                   double *dpz, double *dE);
+/* recapture (Temp:804) -> p-p sweep (Temp:813-842) -> recapture (Temp:844); returns the step's counters */
+int amc_temp_end(amc_ctx *ctx, amc_step_stats *out);
 
 /* ---- outputs -------------------------------------------------------------------------------------------- */
 /* completed_paths / completed_{x,y,z}_paths (Pore:408-413) since the last drain, unsorted */

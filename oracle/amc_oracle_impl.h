@@ -390,6 +390,144 @@ int ORC(cube_sweep)(const amc_params *P, orc_state *S, orc_sink *sink, int32_t s
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
+/* a7 — Temperature_Pore_MC.py walls.  Cases 1-2 are specular WITHOUT bookkeeping (Temp:311-347); cases 3-6 re-emit
+ * the particle in a random direction with an accommodated energy (Temp:349-553).  The random directions
+ * (Temp:132-141: np.random + random Mersenne Twisters) and the gap-wall Debye energy (mpmath.quad, Temp:147-152) are
+ * drawn by the HOST in ascending particle index and handed in; everything deterministic is restated here.
+ * case ids in evaluation order: 3 = case-3 cold plane, 4 = case-3 hot plane, 5 = case-4 gap side wall,
+ * 6 = case-5 bottom plane, 7 = case-5 top plane, 8 = case-6 hot side wall, 9 = case-6 cold side wall.            */
+void ORC(temp_specular)(const amc_params *P, orc_state *S, int64_t *nerr)
+{
+    const int64_t n = S->n;
+    uint8_t *hits = (uint8_t *)malloc((size_t)n + 1);
+    for (int64_t p = 0; p < n; p++) hits[p] = sqrt(S->x[p] * S->x[p] + S->y[p] * S->y[p]) > P->R_oa;   /* Temp:693 */
+    ORC(side_wall)(P, S, hits, P->R_oa_c, 0, NULL, 0, 1, NULL, nerr);                                   /* Temp:694 */
+    for (int64_t p = 0; p < n; p++) {
+        if (S->z[p] < 0) {                                                                   /* Temp:699-700, 311-315 */
+            double t = (S->z[p] - 0.0) / S->vz[p];
+            S->vz[p] = -S->vz[p];
+            S->z[p] = 0.0 + t * S->vz[p];
+        }
+        if (S->z[p] > P->H) {                                                                /* Temp:702-703 */
+            double t = (S->z[p] - P->H) / S->vz[p];
+            S->vz[p] = -S->vz[p];
+            S->z[p] = P->H + t * S->vz[p];
+        }
+    }
+    free(hits);
+}
+
+void ORC(temp_mask)(const amc_params *P, const orc_state *S, int case_id, uint8_t *hits)
+{
+    for (int64_t p = 0; p < S->n; p++) {
+        const double x = S->x[p], y = S->y[p], z = S->z[p], px = S->px[p], py = S->py[p], pz = S->pz[p];
+        const double r2 = x * x + y * y, r02 = px * px + py * py;
+        int h = 0;
+        switch (case_id) {
+        case 3: h = (pz >= P->t_z3_cold) && (z < P->t_z3_cold) && (r2 > P->R_p_sq); break;               /* Temp:708 */
+        case 4: h = (pz <= P->t_z3_hot) && (z > P->t_z3_hot) && (r2 > P->R_p_sq); break;                 /* Temp:713 */
+        case 5: h = (pz < P->t_zgap_hi) && (pz > P->t_zgap_lo) && (r02 <= P->R_g_c_sq) && (r2 > P->R_g_c_sq); break; /* 720 */
+        case 6: h = (r02 >= P->R_p_c_sq) && (z < P->t_zgap_lo) && (pz <= P->t_zgap_hi) && (pz >= P->t_zgap_lo); break; /* 728 */
+        case 7: h = (r02 >= P->R_p_c_sq) && (z > P->t_zgap_hi) && (pz <= P->t_zgap_hi) && (pz >= P->t_zgap_lo); break; /* 734 */
+        case 8: h = (r02 <= P->R_p_c_sq) && (r2 > P->R_p_c_sq) && (z <= P->t_zgap_lo) && (z >= P->t_z3_hot); break;   /* 743 */
+        case 9: h = (r02 <= P->R_p_c_sq) && (r2 > P->R_p_c_sq) && (z < P->t_z3_cold) && (z > P->t_zgap_hi); break;   /* 749 */
+        default: break;
+        }
+        hits[p] = (uint8_t)h;
+    }
+}
+
+static int ORC(temp_is_plane)(int case_id) { return case_id == 3 || case_id == 4 || case_id == 6 || case_id == 7; }
+static double ORC(temp_plane)(const amc_params *P, int case_id)
+{
+    return case_id == 3 ? P->t_z3_cold : case_id == 4 ? P->t_z3_hot : case_id == 6 ? P->t_zgap_lo : P->t_zgap_hi;
+}
+static double ORC(temp_radius)(const amc_params *P, int case_id) { return case_id == 5 ? P->R_g_c : P->R_p_c; }
+
+/* geometry of the hits of one case, in ascending particle index: flight time since contact, contact point, the
+ * INWARD unit normal handed to random_inbounds_direction (Temp:374-375, 442-444) and ok = 0 where the reference's
+ * try-block fails (Temp:472-474).  Returns the number of hits. */
+int64_t ORC(temp_geometry)(const amc_params *P, const orc_state *S, int case_id, const uint8_t *hits, int32_t *idx,
+                           double *t_out, double *contact, double *normal, uint8_t *ok)
+{
+    int64_t k = 0;
+    for (int64_t p = 0; p < S->n; p++) {
+        if (!hits[p]) continue;
+        const double x = S->x[p], y = S->y[p], z = S->z[p], vx = S->vx[p], vy = S->vy[p], vz = S->vz[p];
+        idx[k] = (int32_t)p;
+        ok[k] = 1;
+        if (ORC(temp_is_plane)(case_id)) {
+            const double zp = ORC(temp_plane)(P, case_id);
+            const double t = (z - zp) / vz;                                                  /* Temp:353 */
+            t_out[k] = t;
+            contact[3 * k] = x - vx * t; contact[3 * k + 1] = y - vy * t; contact[3 * k + 2] = zp;   /* Temp:372 */
+            normal[3 * k] = 0; normal[3 * k + 1] = 0;
+            normal[3 * k + 2] = (case_id == 3 || case_id == 6) ? 1.0 : -1.0;                 /* Temp:709,714,730,736 */
+        } else {
+            const double Rc = ORC(temp_radius)(P, case_id);
+            const double a = SQ(-vx) + SQ(-vy);                                              /* Temp:436 */
+            const double b = 2 * (x * (-vx) + y * (-vy));
+            const double c = SQ(x) + SQ(y) - SQ(Rc);
+            const double disc2 = SQ(b) - 4 * a * c;
+            if (a == 0.0 || disc2 < 0.0 || disc2 != disc2) {
+                ok[k] = 0; t_out[k] = 0;
+                contact[3 * k] = contact[3 * k + 1] = contact[3 * k + 2] = 0;
+                normal[3 * k] = normal[3 * k + 1] = normal[3 * k + 2] = 0;
+            } else {
+                const double sq = sqrt(disc2);
+                const double t1 = (-b + sq) / (2 * a), t2 = (-b - sq) / (2 * a);
+                const double t = (t1 < t2) ? t1 : t2;                                        /* Temp:439 */
+                t_out[k] = t;
+                const double cx = x - vx * t, cy = y - vy * t, cz = z - vz * t;              /* Temp:440 */
+                contact[3 * k] = cx; contact[3 * k + 1] = cy; contact[3 * k + 2] = cz;
+                /* normalized_norm_vect = [col_x, col_y, 0] / Rc ; the sampler gets its negation (Temp:442-444) */
+                normal[3 * k] = -(cx / Rc); normal[3 * k + 1] = -(cy / Rc); normal[3 * k + 2] = -(0.0 / Rc);
+            }
+        }
+        k++;
+    }
+    return k;
+}
+
+/* re-emission for the hits of one case (Temp:377-403, 446-471, 516-541): dir = unit direction per hit, Es = surface
+ * energy per hit; writes the per-hit z-momentum and energy changes (summed by the caller in hit order, as the
+ * reference accumulates them) and returns the number of hits counted into num_collisions_per_step. */
+int64_t ORC(temp_apply)(const amc_params *P, orc_state *S, int case_id, int64_t nh, const int32_t *idx, const double *t_in,
+                        const double *contact, const uint8_t *ok, const double *dir, const double *Es, double *dpz,
+                        double *dE, orc_sink *sink, int32_t step, int64_t *nerr)
+{
+    const double m = P->argon_mass;
+    const double alpha = (case_id == 5) ? P->alpha_gap : P->alpha_coated;
+    for (int64_t k = 0; k < nh; k++) {
+        const int64_t p = idx[k];
+        dpz[k] = 0; dE[k] = 0;
+        if (!ok[k]) { if (nerr) (*nerr)++; continue; }                                       /* Temp:472-474 */
+        const double t = t_in[k];
+        const double vx = S->vx[p], vy = S->vy[p], vz = S->vz[p];
+        const double v_magnitude = sqrt(SQ(vx) + SQ(vy) + SQ(vz));                           /* Temp:377 */
+        const double old_pz = m * vz;                                                        /* Temp:378 */
+        const double E = 0.5 * m * SQ(v_magnitude);                                          /* Temp:128-129,379 */
+        const double diff = Es[k] - E;                                                       /* Temp:380 */
+        const double Enew = E + diff * alpha;                                                /* Temp:381 */
+        const double mag = sqrt(Enew * 2 / m);                                               /* Temp:383 */
+        dE[k] = Enew - E;                                                                    /* Temp:384 */
+        const double wvx = dir[3 * k] * mag, wvy = dir[3 * k + 1] * mag, wvz = dir[3 * k + 2] * mag;   /* Temp:386 */
+        dpz[k] = m * wvz - old_pz;                                                           /* Temp:387-388 */
+        if (S->flag[p]) {                                                                    /* Temp:391-395 */
+            orc_emit(sink, step, case_id + 1, 0, (int32_t)p, -1, 0,
+                     fabs(S->d[p] - fabs(sqrt(SQ(vx) + SQ(vy) + SQ(vz)) * t)), fabs(S->dx[p] - fabs(vx * t)),
+                     fabs(S->dy[p] - fabs(vy * t)), fabs(S->dz[p] - fabs(vz * t)));
+        } else {
+            S->flag[p] = 1;
+        }
+        S->d[p] = 0; S->dx[p] = 0; S->dy[p] = 0; S->dz[p] = 0;                               /* Temp:398-401 */
+        S->x[p] = contact[3 * k]; S->y[p] = contact[3 * k + 1]; S->z[p] = contact[3 * k + 2];   /* Temp:402 */
+        S->vx[p] = wvx; S->vy[p] = wvy; S->vz[p] = wvz;                                      /* Temp:403 */
+    }
+    return nh;                                                                               /* Temp:411,482,552 */
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
 /* one iteration of the reference's time loop: Cube:175-338 / Pore:416-557 (Temp's deterministic part)       */
 int ORC(timestep)(const amc_params *P, orc_state *S, double dt, orc_sink *sink, int32_t step, amc_step_stats *st)
 {

@@ -279,6 +279,15 @@ def dump(step, ncoll=None, lists=None):
     if step in _snap_steps:
         for k in _KEYS:
             _store['s%%04d_%%s' %% (step, k)] = arr(k)
+    if step == -1:
+        import random as _r
+        st = np.random.get_state()
+        _store['rng_np_keys'] = np.asarray(st[1], dtype=np.uint32)
+        _store['rng_np_pos'] = np.int64(st[2])
+        _store['rng_np_gauss'] = np.array([st[3], st[4]], dtype=np.float64)
+        ps = _r.getstate()
+        _store['rng_py_state'] = np.asarray(ps[1], dtype=np.uint64)
+        _store['rng_py_version'] = np.int64(ps[0])
     st = _store.setdefault('per_step', [])
     if step >= 0:
         vx, vy, vz = arr('x_velocities'), arr('y_velocities'), arr('z_velocities')
@@ -373,6 +382,28 @@ def gen_pore(tag, K, sigma_mult, slice_, steps, snaps):
                 f"step_pore_{tag}.npz", dict(K=K, sigma_mult=sigma_mult, slice=slice_, steps=steps))
 
 
+def gen_temp(tag, K, sigma_mult, slice_, steps, snaps):
+    subs = [
+        (r"^num_molecules\s+= np\.round\(", f"num_molecules               = np.int64({K})"),
+        (r"^sigma\s+= 3\.6", f"sigma                       = 3.6 * 10**(-19) * {sigma_mult}"),
+        (r"^nmft_slice\s+= 1000", f"nmft_slice                  = {slice_}"),
+        (r"^        for step in range\(num_timesteps\):", f"        for step in range({steps}):"),
+    ]
+    inserts = [
+        (r"^        for step in range\(\d+\):", "before", "_golden_hook.dump(-1)"),
+        (r"^            print\('   ',num_collisions_per_step\.value,' collisions from this timestep'\)", "after",
+         "_golden_hook.dump(step, num_collisions_per_step.value, [completed_paths])"),
+        (r"^        print\('Num of measured full paths total: '", "after",
+         "_golden_hook.finish([completed_paths, completed_x_paths, completed_y_paths, completed_z_paths], "
+         "dict(dt=dt, collision_range=collision_range, total_cols=total_cols, total_errs=total_errs, "
+         "momentum=[float(v) for v in momentum_z_change_per_step], "
+         "energy_cold=[float(v) for v in energy_transfer_cold_per_step], "
+         "energy_hot=[float(v) for v in energy_transfer_hot_per_step]))"),
+    ]
+    run_patched("Temperature_Pore_MC.py", subs, inserts, set(snaps) | {-1},
+                f"step_temp_{tag}.npz", dict(K=K, sigma_mult=sigma_mult, slice=slice_, steps=steps))
+
+
 def gen_cube(tag, K, sigma_mult, steps, snaps):
     subs = [
         (r"^num_molecules\s+= np\.round\(", f"num_molecules       = np.int64({K})"),
@@ -406,6 +437,8 @@ def main():
         gen_cube("dense", K=2500, sigma_mult=36, steps=25, snaps=[0, 1, 10, 24])
     if a.only in ("all", "pore"):
         gen_pore("a", K=1500, sigma_mult=100, slice_=1, steps=40, snaps=[0, 1, 5, 20, 39])
+    if a.only in ("all", "temp"):
+        gen_temp("a", K=2000, sigma_mult=100, slice_=1, steps=30, snaps=[0, 1, 10, 29])
 
 
 if __name__ == "__main__":

@@ -145,6 +145,62 @@ class Oracle:
                                    C.c_int32(phase), C.byref(n), C.byref(e))
         return rc, n.value, e.value
 
+    # -- Temperature_Pore_MC.py (energised walls): deterministic parts in C, RNG / mpmath on the host --------
+    def temp_specular(self):
+        e = C.c_int64(0)
+        self._fn("temp_specular")(C.byref(self.p), C.byref(self._state), C.byref(e))
+        return e.value
+
+    def wall_hits(self, case):
+        n = self.n
+        hits = np.zeros(n + 1, dtype=np.uint8)
+        self._fn("temp_mask")(C.byref(self.p), C.byref(self._state), C.c_int(case), hits.ctypes.data_as(C.POINTER(C.c_uint8)))
+        nh = int(hits[:n].sum())
+        idx = np.zeros(max(1, nh), dtype=np.int32)
+        t = np.zeros(max(1, nh)); contact = np.zeros((max(1, nh), 3)); normal = np.zeros((max(1, nh), 3))
+        ok = np.zeros(max(1, nh), dtype=np.uint8)
+        f = self._fn("temp_geometry")
+        f.restype = C.c_int64
+        got = f(C.byref(self.p), C.byref(self._state), C.c_int(case), hits.ctypes.data_as(C.POINTER(C.c_uint8)),
+                idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(t), _dp(contact), _dp(normal),
+                ok.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert got == nh
+        self._pending = (case, nh, idx, t, contact, ok)
+        return idx[:nh], normal[:nh], contact[:nh, 2].copy(), ok[:nh].astype(bool)
+
+    def wall_apply(self, case, dirs, Es):
+        pc, nh, idx, t, contact, ok = self._pending
+        assert pc == case
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        Es = np.ascontiguousarray(Es, dtype=np.float64)
+        dpz = np.zeros(max(1, nh)); dE = np.zeros(max(1, nh))
+        nerr = C.c_int64(0)
+        f = self._fn("temp_apply")
+        f.restype = C.c_int64
+        cnt = f(C.byref(self.p), C.byref(self._state), C.c_int(case), C.c_int64(nh), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                _dp(t), _dp(contact), ok.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(dirs), _dp(Es), _dp(dpz), _dp(dE),
+                C.byref(self._sink), C.c_int32(self.step), C.byref(nerr))
+        self._temp_wall_count += cnt
+        self._temp_errs += nerr.value
+        return dpz[:nh], dE[:nh]
+
+    def temp_timestep(self, dt, sampler, energies):
+        """One iteration of Temp:662-853.  Returns (stats dict, momentum, energy_cold, energy_hot, had flags)."""
+        from argon_monte_carlo_amd.energised import drive_energised_cases
+        before = self._sink.n
+        self._temp_wall_count = 0
+        self._temp_errs = 0
+        self.drift(dt, True)                                        # Temp:672-683
+        self._temp_errs += self.temp_specular()                     # Temp:693-703
+        res = drive_energised_cases(self, sampler, energies)        # Temp:705-758
+        oob1 = self.bounds(True)                                    # Temp:804
+        rc, npp, _ = self.sweep()                                   # Temp:813-842
+        oob2 = self.bounds(True)                                    # Temp:844
+        st = dict(n_pp=npp, n_wall=self._temp_wall_count, n_oob_walls=oob1, n_oob_pp=oob2,
+                  n_paths=self._sink.n - before, n_fp_errors=self._temp_errs)
+        self.step += 1
+        return (rc, st) + res
+
     # -- outputs ------------------------------------------------------------------------------------------
     def paths(self):
         """completed-path records so far, in the reference's append order."""

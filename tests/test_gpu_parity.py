@@ -262,3 +262,49 @@ def test_run_many_steps_equals_stepwise(Engine):
     assert tot["n_pp"] == acc
     assert_state_equal(a.download(), b.download(), "run")
     a.close(); b.close()
+
+
+# ---------------------------------------------------------------------------------------------- Temperature_Pore_MC
+def test_energised_walls_match_oracle_and_reference(O, golden_dir):
+    """Temp:662-853 on the GPU (kernels + host RNG/mpmath sliver) == oracle `mul` bit for bit, every step, including
+    the per-step z-momentum / energy transfer; and == the reference's own per-step values within 1e-6 relative."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+    from argon_monte_carlo_amd.engine import EnergisedEngine
+    from tests.test_oracle_steps import restore_rngs, temp_setup
+    Gs = load_step(golden_dir, "step_temp_a.npz")
+    p, c, dt, _, energies = temp_setup(Gs)
+    init = [Gs[f"s-001_{k}"] for k in STATE_KEYS]
+    p.reserved0 |= 1
+    eng = EnergisedEngine(p)
+    eng.upload(*init[:10], flag=init[10])
+    orc = O.Oracle(p, mode="mul")
+    orc.upload(*init[:10], flag=init[10])
+    # two independent copies of the reference's RNG streams, one per implementation
+    restore_rngs(Gs)
+    st_np, st_py = np.random.get_state(), random.getstate()
+    rs_dev, rs_orc = np.random.RandomState(), np.random.RandomState()
+    rs_dev.set_state(st_np); rs_orc.set_state(st_np)
+    py_dev, py_orc = random.Random(), random.Random()
+    py_dev.setstate(st_py); py_orc.setstate(st_py)
+    s_dev, s_orc = DirectionSampler(rs_dev, py_dev), DirectionSampler(rs_orc, py_orc)
+    per = Gs["per_step"]
+    nwall = 0
+    for s in range(per.shape[0]):
+        st, m, ec, eh, hm, hc, hh = eng.temp_timestep(dt, s_dev, energies)
+        rc, so, m2, ec2, eh2, hm2, hc2, hh2 = orc.temp_timestep(dt, s_orc, energies)
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+            assert st[k] == so[k], (s, k, st, so)
+        assert (m, ec, eh, hm, hc, hh) == (m2, ec2, eh2, hm2, hc2, hh2), s
+        assert st["n_pp"] + st["n_wall"] == int(per[s, 1])
+        nwall += st["n_wall"]
+        assert_state_equal(eng.download(), orc.state(), ctx=("temp", s))
+        np.testing.assert_allclose(m, Gs["momentum"][s], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(ec, Gs["energy_cold"][s], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(eh, Gs["energy_hot"][s], rtol=1e-6, atol=0)
+    assert nwall > 20
+    rec, ro = eng.drain_paths(sort=True), orc.paths()
+    a, b = paths_of(rec), paths_of(ro)
+    assert a.shape == b.shape and np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+    eng.close()
