@@ -27,6 +27,7 @@ SIGNATURES = {
     "amc_destroy": (None, [_ctx]),
     "amc_last_error": (C.c_char_p, [_ctx]),
     "amc_set_stream": (C.c_int, [_ctx, C.c_void_p]),
+    "amc_use_null_stream": (C.c_int, [_ctx]),
     "amc_synchronize": (C.c_int, [_ctx]),
     "amc_upload": (C.c_int, [_ctx] + [_dp] * 10 + [_u8p]),
     "amc_download": (C.c_int, [_ctx] + [_dp] * 10 + [_u8p]),

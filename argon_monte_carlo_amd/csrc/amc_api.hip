@@ -155,7 +155,7 @@ void amc_destroy(amc_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
                     c->S.pz, c->S.flag, c->d_lay, c->B.sx, c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, c->B.cell_count,
                     c->B.cid, c->B.rank, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
@@ -322,6 +322,16 @@ int amc_set_stream(amc_ctx *c, void *hip_stream)
     amc_prof_collect(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return AMC_OK;
+}
+
+int amc_use_null_stream(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    hipSetDevice(c->device);
+    amc_prof_collect(c);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    c->stream = nullptr;        // HIP's NULL stream
     return AMC_OK;
 }
 

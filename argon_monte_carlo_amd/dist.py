@@ -101,8 +101,12 @@ class ShardedSimulation:
         if engine is None:
             from .engine import ShardEngine
             engine = ShardEngine(params, self.lo, self.hi)
-            if stream_ptr is not None:
-                engine.set_stream(stream_ptr)
+            if stream_ptr is None:
+                # the collectives (and their host staging under gloo) are torch operations: the library's kernels must
+                # run on the same stream, or a table could be read before the kernel that fills it has finished
+                import torch
+                stream_ptr = torch.cuda.current_stream().cuda_stream
+            engine.set_stream(stream_ptr)
         self.engine = engine
         self.comm = comm if comm is not None else TorchComm(rank, world)
         self.max_rounds = 64

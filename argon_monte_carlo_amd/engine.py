@@ -143,7 +143,11 @@ class Engine:
 
     # -- measurement -----------------------------------------------------------------------------------------------
     def set_stream(self, stream_ptr):
-        self._ck(self.lib.amc_set_stream(self._ctx, C.c_void_p(stream_ptr)))
+        """Run on the given hipStream_t; 0 = HIP's NULL stream (torch's default current stream)."""
+        if not stream_ptr:
+            self._ck(self.lib.amc_use_null_stream(self._ctx))
+        else:
+            self._ck(self.lib.amc_set_stream(self._ctx, C.c_void_p(stream_ptr)))
 
     def synchronize(self):
         self._ck(self.lib.amc_synchronize(self._ctx))

@@ -151,6 +151,9 @@ void amc_destroy(amc_ctx *ctx);
 const char *amc_last_error(const amc_ctx *ctx);
 /* Run all subsequent work on this hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream. */
 int amc_set_stream(amc_ctx *ctx, void *hip_stream);
+/* Run on HIP's NULL (legacy default) stream — what torch.cuda.current_stream() is unless the caller changed it; needed
+ * so that torch.distributed collectives and this library's kernels are ordered on one stream. */
+int amc_use_null_stream(amc_ctx *ctx);
 int amc_synchronize(amc_ctx *ctx);
 
 /* ---- state (replaces the module-global ndarrays of Pore:385-400) ----------------------------------------- */

@@ -308,3 +308,70 @@ def test_energised_walls_match_oracle_and_reference(O, golden_dir):
     a, b = paths_of(rec), paths_of(ro)
     assert a.shape == b.shape and np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- the reference-named facade
+def test_facade_pairwise_particles_in_cell_is_a_drop_in(G):
+    """argon_monte_carlo_amd.sim.pairwise_particles_in_cell: the reference's signature, return tuple and side effects."""
+    import multiprocessing
+    from argon_monte_carlo_amd import sim as S
+    off, poff = G["cell_off"], G["cell_path_off"]
+    with pytest.raises(NameError):
+        S.num_collisions_per_step = None
+        S.pairwise_particles_in_cell([], [], [], [], np.ones(2, bool), *[np.zeros(2)] * 4, np.zeros(2, bool), *[np.zeros(2)] * 6)
+    for c in (0, 2, 5, 9):
+        sl = slice(off[c], off[c + 1])
+        counter = multiprocessing.Value('i', 0)
+        S.init_globals(counter)
+        lists = [[], [], [], []]
+        args = [G[f"cell_in_{f}"][sl].copy() for f in FIELDS]
+        args[4] = args[4].astype(bool)
+        res = S.pairwise_particles_in_cell(*lists, np.ones(off[c + 1] - off[c], dtype=bool), *args)
+        assert len(res) == 12 and counter.value == G["cell_ncoll"][c]
+        for f, a in zip(FIELDS, res[1:]):
+            np.testing.assert_allclose(np.asarray(a, dtype=np.float64), G[f"cell_out_{f}"][sl], rtol=1e-9, atol=1e-300)
+        got = np.array(list(zip(*lists)), dtype=np.float64).reshape(-1, 4)
+        np.testing.assert_allclose(got, G["cell_paths"][poff[c]:poff[c + 1]], rtol=1e-9)
+
+
+def test_facade_simulation_reproduces_the_reference_run_and_its_files(golden_dir, tmp_path):
+    """Simulation('pore').timestep() from the reference's initial state: same per-step collision counter, same
+    completed-path multiset, and the 8 histogram text files byte-identical to the ones the reference wrote."""
+    from argon_monte_carlo_amd import outputs as OUT
+    from argon_monte_carlo_amd.sim import Simulation
+    Gs = load_step(golden_dir, "step_pore_a.npz")
+    p, dt = golden_params(Gs, "pore")
+    from argon_monte_carlo_amd import params as PR2
+    _, consts = PR2.pore_params(n=int(Gs["meta_K"]), sigma=3.6 * 10**(-19) * float(Gs["meta_sigma_mult"]))
+    sim = Simulation("pore", params=p, consts=consts)
+    sim.set_state(*[Gs[f"s-001_{k}"] for k in STATE_KEYS])
+    per = Gs["per_step"]
+    for s in range(per.shape[0]):
+        sim.timestep(dt)
+        assert sim.num_collisions_per_step == int(per[s, 1])
+    assert sim.total_cols == int(Gs["total_cols"])
+    assert sorted(sim.completed_paths) == sorted(Gs["completed_paths"].tolist())
+    np.testing.assert_array_equal(sim.x_vals, Gs[f"s{per.shape[0] - 1:04d}_x_vals"])
+    sim.write_outputs(str(tmp_path))
+    for _, fx, fy in OUT.HIST_FILES:
+        for fn in (fx, fy):
+            assert open(tmp_path / fn, "rb").read() == bytes(Gs["file_" + fn]), fn
+    sim.close()
+
+
+def test_facade_temperature_simulation_writes_the_reference_csv(golden_dir, tmp_path):
+    from argon_monte_carlo_amd import params as PR2
+    from argon_monte_carlo_amd.sim import TemperatureSimulation
+    from tests.test_oracle_steps import restore_rngs
+    Gs = load_step(golden_dir, "step_temp_a.npz")
+    p, consts = PR2.pore_params(n=int(Gs["meta_K"]), sigma=3.6 * 10**(-19) * float(Gs["meta_sigma_mult"]), energised=True)
+    sim = TemperatureSimulation(params=p, consts=consts)
+    sim.set_state(*[Gs[f"s-001_{k}"] for k in STATE_KEYS])
+    restore_rngs(Gs)                       # the module-level np.random / random streams, as the reference had them
+    dt = float(Gs["dt"])
+    for s in range(Gs["per_step"].shape[0]):
+        sim.timestep(dt)
+    np.testing.assert_allclose(np.array(sim.momentum_z_change_per_step, dtype=float), Gs["momentum"], rtol=1e-6)
+    sim.write_outputs(str(tmp_path))
+    assert open(tmp_path / "momentum_energy.csv", "rb").read() == bytes(Gs["file_momentum_energy.csv"])
+    sim.close()

@@ -35,13 +35,17 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under argon_monte_carlo_amd/ may import, link or dlopen it."""
     pkg = os.path.join(ROOT, "argon_monte_carlo_amd")
+    bad = re.compile(r"(^\s*(from|import)\s+oracle\b)|liboracle|oracle/|orc_(pow|mul)_", re.M)
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
-            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+            if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 src = open(os.path.join(dirpath, fn)).read()
-                assert "oracle" not in src.lower().replace("# oracle", "").replace("the cpu oracle has both", "") or \
-                    fn in ("amc_device.h",), fn
+                m = bad.search(src)
+                assert m is None or fn == "amc_device.h" and "orc_" in m.group(0), (fn, m.group(0) if m else None)
+    src = open(os.path.join(pkg, "csrc", "Makefile")).read()
+    assert "oracle" not in src
 
 
 def test_params_match_reference_constants(golden_dir):
