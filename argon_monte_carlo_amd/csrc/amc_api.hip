@@ -166,7 +166,8 @@ void amc_destroy(amc_ctx *c)
                     c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
-                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok};
+                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
+                    c->W.ev_gen, c->W.ev_slot, c->W.hist_gen};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -269,23 +270,25 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.sl_key, (size_t)next_pow2(W.max_slots)));
         double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
         for (auto pp : sl) CK(dalloc(pp, ms));
-        CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms));
+        CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms)); CK(dalloc(&W.sl_dirty, ms));
+        CK(dalloc(&W.sl_gen, ms)); CK(dalloc(&W.sl_hits, ms));
         for (int k = 0; k < 10; k++) CK(dalloc(&W.cw_d[k], ms));
         CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
         CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
         CK(dalloc(&W.hist_slot, (size_t)W.max_hist)); CK(dalloc(&W.hist_x, (size_t)W.max_hist));
         CK(dalloc(&W.hist_y, (size_t)W.max_hist)); CK(dalloc(&W.hist_z, (size_t)W.max_hist));
-        CK(dalloc(&W.ov_next, (size_t)W.max_hist));
+        CK(dalloc(&W.ov_next, (size_t)W.max_hist)); CK(dalloc(&W.hist_gen, (size_t)W.max_hist));
         CK(dalloc(&W.ev_phase, (size_t)W.max_events)); CK(dalloc(&W.ev_i, (size_t)W.max_events));
         CK(dalloc(&W.ev_j, (size_t)W.max_events)); CK(dalloc(&W.ev_which, (size_t)W.max_events));
         CK(dalloc(&W.ev_cell, (size_t)W.max_events)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_events));
+        CK(dalloc(&W.ev_gen, (size_t)W.max_events)); CK(dalloc(&W.ev_slot, (size_t)W.max_events));
         // outputs
         long long mp = p->max_paths > 0 ? p->max_paths : (1LL << 20);
         if (mp > 0x7fffffff) mp = 0x7fffffff;
         CK(dalloc(&c->d_rec, (size_t)mp));
         CK(dalloc(&c->d_cnt, 1));
         CK(hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
-        c->out.rec = c->d_rec; c->out.cap = (unsigned)mp; c->out.cnt = c->d_cnt;
+        c->out.rec = c->d_rec; c->out.cap = (unsigned)mp; c->out.cnt = c->d_cnt; c->out.step = 0;
         c->out.nbins = 0; c->out.hist = nullptr; c->out.edges = nullptr; c->out.lo = p->hist_lo; c->out.hi = p->hist_hi;
         if (p->hist_bins > 0 && p->hist_hi > p->hist_lo) {
             const int nb = p->hist_bins;
@@ -419,29 +422,28 @@ static int finish_stats(amc_ctx *c, amc_step_stats *out)
     delta_stats(now, c->h_prev, &st);
     c->h_prev = now;
     if (out) *out = st;
-    if (now.flags & 7ULL) {
+    if (now.flags & 5ULL) {     // candidate / resolve work-space overflow; a full path-record buffer (bit1) only stops recording
         const unsigned long long f = now.flags;
         // clear the sticky flags on the device so that a later call can succeed after the caller drained / resized
         unsigned long long zero = 0;
         hipMemcpyAsync(&c->d_cnt->flags, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream);
         hipStreamSynchronize(c->stream);
         c->h_prev.flags = 0;
-        return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 2 path records, 4 resolve)", f);
+        return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 4 resolve work space)", f);
     }
     if (st.n_fp_errors > 0 && c->P.geometry != AMC_GEOM_PORE_ENERGISED && !(c->P.reserved1 & 1))
         return amc_fail(c, AMC_ERR_FP, "%lld event(s) where the reference raises FloatingPointError", (long long)st.n_fp_errors);
     return AMC_OK;
 }
 
-static int enqueue_sweep(amc_ctx *c)
+static int enqueue_sweep(amc_ctx *c, bool counted = false)
 {
-    AMC_HIP(c, amc_launch_bin(c));
+    AMC_HIP(c, amc_launch_bin(c, counted));
     AMC_HIP(c, amc_launch_detect(c));
     AMC_HIP(c, amc_launch_resolve(c));
     return AMC_OK;
 }
 
-static __global__ void k_next_step(amc_dev_counters *cnt) { cnt->step += 1; }
 
 static int enqueue_step(amc_ctx *c, double dt)
 {
@@ -449,17 +451,18 @@ static int enqueue_step(amc_ctx *c, double dt)
     int rc;
     if (g == AMC_GEOM_CELL) {
         if ((rc = enqueue_sweep(c))) return rc;
-    } else if (g == AMC_GEOM_CUBE) {
-        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
-        if ((rc = enqueue_sweep(c))) return rc;
-    } else if (g == AMC_GEOM_PORE) {
-        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS, 0));
-        if ((rc = enqueue_sweep(c))) return rc;
-        AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
+    } else if (g == AMC_GEOM_CUBE || g == AMC_GEOM_PORE) {
+        // the streaming pass also counts the particles into the detection grid when it covers all of them
+        const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
+        if (fuse) AMC_HIP(c, amc_launch_bin_clear(c));
+        const int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
+        AMC_HIP(c, amc_launch_stream(c, dt, st, 0, fuse));
+        if ((rc = enqueue_sweep(c, fuse))) return rc;
+        if (g == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
     } else {
         return amc_fail(c, AMC_ERR_INVALID, "energised walls need the host handshake: use the Python driver (amc_wall_hits/apply)");
     }
-    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    c->out.step++;
     return AMC_OK;
 }
 
@@ -576,6 +579,7 @@ int amc_reset_outputs(amc_ctx *c)
     AMC_HIP(c, hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
     AMC_HIP(c, hipStreamSynchronize(c->stream));
     memset(&c->h_prev, 0, sizeof c->h_prev);
+    c->out.step = 0;
     return AMC_OK;
 }
 
@@ -759,7 +763,7 @@ int amc_temp_end(amc_ctx *c, amc_step_stats *out)
     int rc = enqueue_sweep(c);                                      // Temp:813-842
     if (rc) return rc;
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));        // Temp:844
-    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    c->out.step++;
     return finish_stats(c, out);
 }
 
@@ -899,7 +903,7 @@ int amc_mg_finish(amc_ctx *c, amc_step_stats *out)
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->P.geometry == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));
-    hipLaunchKernelGGL(k_next_step, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    c->out.step++;
     return finish_stats(c, out);
 }
 

@@ -34,6 +34,7 @@ struct amc_out {
     int nbins;
     double lo, hi;
     amc_dev_counters *cnt;
+    int step;                           // index of the current step (record key), set by the host per launch
 };
 
 // np.histogram(a, bins=n, range=(lo,hi)) bin of one value (numpy/lib/_histograms_impl.py uniform-bin path):
@@ -65,7 +66,7 @@ AMC_DEV void amc_emit(const amc_out &o, int phase, long long cell, int i, int j,
         unsigned int k = atomicAdd(&o.cnt->path_count, 1u);
         if (k < o.cap) {
             amc_path_record r;
-            r.step = o.cnt->step; r.phase = phase; r.cell = cell; r.i = i; r.j = j; r.which = which; r.reserved = 0;
+            r.step = o.step; r.phase = phase; r.cell = cell; r.i = i; r.j = j; r.which = which; r.reserved = 0;
             r.total = tot; r.px = px; r.py = py; r.pz = pz;
             o.rec[k] = r;
         } else {

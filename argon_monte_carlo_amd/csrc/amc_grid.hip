@@ -86,32 +86,23 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_block(const int *__restrict__ i
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(SCAN_T) void k_scan_sums(int *__restrict__ block_sums, int nb, int *__restrict__ out_total)
+// second (last) scan kernel: every block sums the raw totals of the blocks before it (a few hundred ints) and adds
+// that offset to its tile; the last block also writes the grand total behind the table
+__global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, int n, const int *__restrict__ block_sums, int nb)
 {
-    // single block; nb <= SCAN_T * 64 handled by a serial carry over chunks of SCAN_T
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
+    __shared__ int s_off, s_tot;
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_T) part += block_sums[b];
+    int total;
+    block_exclusive_scan_1024(part, &total);
+    if (threadIdx.x == 0) { s_off = total; s_tot = total + block_sums[blockIdx.x]; }
     __syncthreads();
-    for (int base = 0; base < nb; base += SCAN_T) {
-        const int i = base + threadIdx.x;
-        const int v = (i < nb) ? block_sums[i] : 0;
-        int total;
-        const int ex = block_exclusive_scan_1024(v, &total);
-        if (i < nb) block_sums[i] = ex + carry;
-        __syncthreads();
-        if (threadIdx.x == 0) carry += total;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *out_total = carry;
-}
-
-__global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, int n, const int *__restrict__ block_sums)
-{
-    const int add = block_sums[blockIdx.x];
+    const int add = s_off;
     const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++)
         if (base + k < n) out[base + k] += add;
+    if ((int)blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = s_tot;
 }
 
 __global__ __launch_bounds__(256) void k_bin_scatter(const double *__restrict__ x, const double *__restrict__ y,
@@ -216,24 +207,31 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-hipError_t amc_launch_bin(amc_ctx *c)
+hipError_t amc_launch_bin_clear(amc_ctx *c)
+{
+    if (c->allpairs) return hipSuccess;
+    return hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (size_t)c->G.ncells, c->stream);
+}
+
+hipError_t amc_launch_bin(amc_ctx *c, bool counted)
 {
     if (c->allpairs) return hipSuccess;
     const long long n = c->n;
     const int nc = c->G.ncells;
     hipError_t e;
-    amc_prof_begin(c, AMC_K_BIN_COUNT);
-    e = hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (size_t)nc, c->stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bin_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z, n,
-                       c->G, c->B.cell_count, c->B.cid, c->B.rank, c->d_cnt);
-    amc_prof_end(c);
+    if (!counted) {
+        amc_prof_begin(c, AMC_K_BIN_COUNT);
+        e = amc_launch_bin_clear(c);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_bin_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z, n,
+                           c->G, c->B.cell_count, c->B.cid, c->B.rank, c->d_cnt);
+        amc_prof_end(c);
+    }
     const int nb = (nc + SCAN_BLOCK - 1) / SCAN_BLOCK;
     amc_prof_begin(c, AMC_K_BIN_SCAN);
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(SCAN_T), 0, c->stream, c->B.cell_count, c->B.cell_start, nc,
                        c->scan_tmp);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, c->stream, c->scan_tmp, nb, c->B.cell_start + nc);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, c->stream, c->B.cell_start, nc, c->scan_tmp);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(SCAN_T), 0, c->stream, c->B.cell_start, nc, c->scan_tmp, nb);
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_BIN_SCATTER);
     hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z,

@@ -45,7 +45,9 @@ struct amc_resolve_ws {
     unsigned long long *sl_key;                    // sort keys (label<<32 | particle)
     int *order;                                    // slots sorted by (label, particle)
     double *sl_x, *sl_y, *sl_z, *sl_vx, *sl_vy, *sl_vz, *sl_d, *sl_dx, *sl_dy, *sl_dz;
-    uint8_t *sl_flag, *sl_moved;
+    uint8_t *sl_flag, *sl_moved, *sl_dirty;
+    int *sl_gen, *sl_hits;    // round in which the slot's cluster was last emulated; collisions counted on the slot
+    int *ev_gen, *ev_slot, *hist_gen;   // round tags: results of a re-emulated cluster are superseded, not erased
     double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
     int *cw_tmp, *cw_pidx;
     uint8_t *cw_flag, *cw_moved;
@@ -132,8 +134,9 @@ void amc_prof_collect(amc_ctx *c);
 #define AMC_ST_BOUNDS 4
 
 // launchers (each enqueues on c->stream; returns hipError_t of the launch)
-hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot);
-hipError_t amc_launch_bin(amc_ctx *c);                 // count + scan + scatter over all n particles
+hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin = false);
+hipError_t amc_launch_bin_clear(amc_ctx *c);           // zero the per-cell counters (before a fused-count stream pass)
+hipError_t amc_launch_bin(amc_ctx *c, bool counted = false);   // [count +] scan + scatter over all n particles
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c);              // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
@@ -145,5 +148,5 @@ hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, 
 struct amc_resolve_ctl {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
     int rounds, ncand, active, ok, edges_done;
-    int nslots0;
+    int nslots0, hist_begin, cur_round;
 };

@@ -43,6 +43,7 @@ struct rs_args {
     long long n;
     int allpairs;
     int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
+    int allow_mono;           // small sweeps may run validation + commit inside resolve_A (saves three kernels' latency)
     int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
     double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
@@ -53,7 +54,9 @@ struct rs_args {
 struct rs_shared {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
     int rounds, ncand, active, ok, edges_done;
-    int nslots0;              // slots that existed (and have labels in W.sl_label) when resolve_A handed over
+    int nslots0;              // slots that existed (and have labels in W.sl_label) when a resolve kernel handed over
+    int hist_begin;           // first history entry of the current round (older ones were validated already)
+    int cur_round;
 };
 
 // working set of the multi-particle clusters (LDS pool or global fallback), indexed by sorted rank
@@ -100,6 +103,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
         const int e = atomicAdd(&sh->nev, 1);
         if (e < W.max_events) {
             W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
+            W.ev_gen[e] = sh->cur_round; W.ev_slot[e] = si;
             W.ev_val[4 * e + 0] = tot; W.ev_val[4 * e + 1] = px; W.ev_val[4 * e + 2] = py; W.ev_val[4 * e + 3] = pz;
         } else {
             sh->ovf = 1;
@@ -112,9 +116,10 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
         atomicAdd(&sh->nfp, 1);     // the reference would raise FloatingPointError here (Pore:11,185)
         return false;
     }
-    atomicAdd(&sh->nhits, 1);
+    W.sl_hits[si] += 1;         // only the thread that emulates this cluster touches its slots
     const int h = atomicAdd(&sh->nhist, 2);
     if (h + 1 < W.max_hist) {
+        W.hist_gen[h] = sh->cur_round; W.hist_gen[h + 1] = sh->cur_round;
         W.hist_slot[h] = sj; W.hist_x[h] = p1.x; W.hist_y[h] = p1.y; W.hist_z[h] = p1.z;
         W.hist_slot[h + 1] = si; W.hist_x[h + 1] = p2.x; W.hist_y[h + 1] = p2.y; W.hist_z[h + 1] = p2.z;
     } else {
@@ -281,6 +286,22 @@ AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int
     }
 }
 
+// smallest layer >= from that holds at least two members whose K.tmp has all bits of `need` set (0 = any member)
+AMC_DEV int rs_next_layer(const rs_work &K, int b, int e, const double *v, int need, double d, double inv_d, double ov,
+                          int n, int from)
+{
+    int best = -1;
+    for (int a = b + 1; a < e; a++) {
+        if ((K.tmp[a] & need) != need) continue;
+        for (int c = b; c < a; c++) {
+            if ((K.tmp[c] & need) != need) continue;
+            const int l = rs_next_common(v[a], v[c], d, inv_d, ov, n, from);
+            if (l >= 0 && (best < 0 || l < best)) best = l;
+        }
+    }
+    return best;
+}
+
 AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
 {
     const amc_params &P = A.P;
@@ -288,46 +309,27 @@ AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &
         for (int a = b + 1; a < e; a++)                                                     // Pore:168-169
             for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
     } else if (P.geometry == AMC_GEOM_CUBE) {
-        for (int lx = 0; lx < P.nx; lx++) {
+        // Cube:231-238 for a cluster: only layers that hold at least two members can do anything, so the next such
+        // layer is found from the member pairs (rs_next_common) instead of walking all nx*ny*nz cells.  K.tmp bit0/1/2 =
+        // the in_x / in_y / in_z masks, each taken when its layer starts (they stay stale inside it, as in the reference).
+        for (int lx = rs_next_layer(K, b, e, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
+             lx = rs_next_layer(K, b, e, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1)) {
             const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;               // Cube:233
-            int cnt = 0;
-            {   // skip ahead: no layer below floor(min x / dx) - 1 can hold a member
-                double vmin = K.x[b];
-                for (int a = b + 1; a < e; a++) vmin = K.x[a] < vmin ? K.x[a] : vmin;
-                const double f = floor(vmin / P.dx) - 1.0;
-                if (f > (double)lx && f < 1.0e9) { lx = (int)f - 1; continue; }
-            }
-            for (int a = b; a < e; a++) {
-                const double v = K.x[a];
-                const int in = (xlo < v) && (v < xhi);
-                K.tmp[a] = in;
-                cnt += in;
-            }
-            if (cnt < 2) continue;
-            for (int ly = 0; ly < P.ny; ly++) {
+            for (int a = b; a < e; a++) K.tmp[a] = ((xlo < K.x[a]) && (K.x[a] < xhi)) ? 1 : 0;
+            for (int ly = rs_next_layer(K, b, e, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
+                 ly = rs_next_layer(K, b, e, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1)) {
                 const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;           // Cube:235
-                cnt = 0;
                 for (int a = b; a < e; a++) {
-                    int t = K.tmp[a] & 1;
-                    if (t) {
-                        const double v = K.y[a];
-                        if ((ylo < v) && (v < yhi)) { t |= 2; cnt++; }
-                    }
-                    K.tmp[a] = t;
+                    const int t = K.tmp[a] & 1;
+                    K.tmp[a] = t | ((t && (ylo < K.y[a]) && (K.y[a] < yhi)) ? 2 : 0);
                 }
-                if (cnt < 2) continue;
-                for (int lz = 0; lz < P.nz; lz++) {
+                for (int lz = rs_next_layer(K, b, e, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
+                     lz = rs_next_layer(K, b, e, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1)) {
                     const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;       // Cube:237
-                    cnt = 0;
                     for (int a = b; a < e; a++) {
-                        int t = K.tmp[a] & 3;
-                        if (t == 3) {
-                            const double v = K.z[a];
-                            if ((zlo < v) && (v < zhi)) { t |= 4; cnt++; }
-                        }
-                        K.tmp[a] = t;
+                        const int t = K.tmp[a] & 3;
+                        K.tmp[a] = t | ((t == 3 && (zlo < K.z[a]) && (K.z[a] < zhi)) ? 4 : 0);
                     }
-                    if (cnt < 2) continue;
                     const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
                     for (int a = b + 1; a < e; a++) {
                         if (K.tmp[a] != 7) continue;
@@ -461,6 +463,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
             if (h2 == h) continue;
             const int s2 = W.hist_slot[h2];
+            if (W.hist_gen[h2] != W.sl_gen[s2]) continue;     // position of an emulation that was redone since
             if (label[s2] == lme) continue;
             const double ax = W.hist_x[h2] - x, ay = W.hist_y[h2] - y, az = W.hist_z[h2] - z;
             if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
@@ -485,6 +488,7 @@ AMC_DEV int rs_hist_cell(const rs_args &A, const amc_grid &G, int h)
 
 #define RS_NS 2048             // slot labels / sizes kept in LDS
 #define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
+#define RS_SMALL 640           // candidate pairs up to which resolve_A does everything itself
 
 // MODE 0: first round only (claim, label, emulate), validation + commit are the wide kernels that follow
 // MODE 1: continuation: if the wide validation found merges, run the remaining rounds (validation in-kernel)
@@ -499,6 +503,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL];
     __shared__ uint8_t pool_flag[RS_POOL], pool_moved[RS_POOL];
     __shared__ int s_label[RS_NS], s_size[RS_NS];
+    __shared__ unsigned char s_dirty[RS_NS];
     __shared__ int s_lay[RS_LAY];
     const amc_resolve_ws &W = A.W;
     const int tid = threadIdx.x;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         if (tid == 0) {
             sh.nslots = 0; sh.nedges = 0; sh.nhist = 0; sh.nev = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
             sh.nfp = 0; sh.ovf = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
-            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0;
+            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0; sh.nslots0 = 0;
             cnt->cand_count = 0;
             if (ncand == 0) *ctl = sh;
         }
@@ -525,14 +530,18 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         if (ncand == 0) return;     // uniform: nothing to resolve this sweep
     }
 
+    // MODE 2 always, MODE 0 for small sweeps: validation and commit in this kernel (the wide kernels then find
+    // ctl.active == 0 and exit); large sweeps hand over after the first round
+    const bool mono = (MODE == 2) || (MODE == 0 && A.allow_mono && ncand <= RS_SMALL);
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
     V.p = W.sl_p;
-    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS; }
-    else { V.label = W.sl_label; V.size = W.sl_tmp; V.cap = W.max_slots; }
+    unsigned char *vdirty;
+    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS; vdirty = s_dirty; }
+    else { V.label = W.sl_label; V.size = W.sl_tmp; V.cap = W.max_slots; vdirty = W.sl_dirty; }
     // grid layer tables -> LDS (every validation probe reads them)
     amc_grid G = A.G;
-    if (MODE != 0 && !A.allpairs && 3 * G.gz <= RS_LAY) {
+    if ((MODE != 0 || mono) && !A.allpairs && 3 * G.gz <= RS_LAY) {
         for (int k = tid; k < 3 * G.gz; k += RS_T) s_lay[k] = A.G.lay_lo[k];     // the three tables are contiguous
         G.lay_lo = s_lay; G.lay_n = s_lay + G.gz; G.lay_off = s_lay + 2 * G.gz;
     }
@@ -550,11 +559,6 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             W.cand_sj[k] = W.slot_of[W.cand_j[k]];
         }
         __syncthreads();
-    } else {
-        // the overlay still holds the first round's entries: clear it before this kernel's own rounds
-        const int nh0 = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        for (int h = tid; h < nh0; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
-        __syncthreads();
     }
     RS_STAMP(0);
 
@@ -567,16 +571,17 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         __syncthreads();
         // ---- per-round reset; new merge edges: particle ids -> slot ids -------------------------------------------------
         for (int s = tid; s < ns; s += RS_T) {
-            W.sl_moved[s] = 0;
             V.label[s] = s;
             V.size[s] = 0;
+            vdirty[s] = (rounds == 1);          // round 1 emulates everything; later rounds only what the new edges touch
         }
         for (int k = edges_done + tid; k < nedges; k += RS_T) {
             W.edge_a[k] = W.slot_of[W.edge_a[k]];
             W.edge_b[k] = W.slot_of[W.edge_b[k]];
         }
+        const int edges_new = edges_done;
         edges_done = nedges;
-        if (tid == 0) { sh.nhist = 0; sh.nev = 0; sh.nhits = 0; sh.nfp = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; }
+        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = sh.nhist < W.max_hist ? sh.nhist : W.max_hist; }
         __syncthreads();
         // ---- connected components by label propagation (label = lowest slot id of the cluster) -------------------------
         for (;;) {
@@ -593,13 +598,23 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         // ---- cluster sizes, accumulated on the label slot ------------------------------------------------------------------
         for (int s = tid; s < ns; s += RS_T) atomicAdd(&V.size[V.label[s]], 1);
+        // clusters touched by the merge edges of the previous validation are re-emulated; everything else keeps its
+        // results, events and history (tagged with the round they were produced in)
+        for (int k = edges_new + tid; k < nedges; k += RS_T) {
+            const int sa = W.edge_a[k], sb = W.edge_b[k];
+            if (sa >= 0 && sa < ns) vdirty[V.label[sa]] = 1;
+            if (sb >= 0 && sb < ns) vdirty[V.label[sb]] = 1;
+        }
+        __syncthreads();
+        for (int s = tid; s < ns; s += RS_T)
+            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; W.sl_hits[s] = 0; }
         __syncthreads();
         RS_STAMP(1);
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
         unsigned long long *keys = lds_keys;
         for (int s = tid; s < ns; s += RS_T) {
             if (V.label[s] == s) atomicAdd(&sh.nclusters, 1);
-            if (V.size[V.label[s]] >= 3) {
+            if (V.size[V.label[s]] >= 3 && vdirty[V.label[s]]) {
                 const int k = atomicAdd(&sh.ncomplex, 1);
                 const unsigned long long key = ((unsigned long long)(unsigned)V.label[s] << 32) | (unsigned)V.p[s];
                 if (k < RS_SORT_LDS) keys[k] = key; else W.sl_key[k] = key;
@@ -610,7 +625,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         for (int k = tid; k < ncand; k += RS_T) {
             const int si = W.cand_si[k], sj = W.cand_sj[k];
             if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
-            if (V.size[V.label[si]] != 2) continue;
+            if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
             rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
         }
         RS_STAMP(7);
@@ -660,11 +675,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         __syncthreads();
         RS_STAMP(3);
         const int nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        if (MODE == 0 || (MODE == 1 && A.single_round)) {
+        if (!mono && (MODE == 0 || (MODE == 1 && A.single_round))) {
             // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
             if (V.label != W.sl_label)
                 for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
-            for (int h = tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
             if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.nslots0 = ns; *ctl = sh; }
             RS_STAMP(4);
@@ -673,15 +688,14 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         // ---- validate: every new position against everything outside its cluster ------------------------------------------------
         if (!A.allpairs) {
-            for (int h = tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
-            for (int h = tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);
-            __syncthreads();
-            for (int h = tid; h < nh; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
+            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);
         } else {
             // no grid (single cell / small N): brute force against all particles and all history entries
-            for (long long w = tid; w < (long long)nh * A.n; w += RS_T) {
-                const int h = (int)(w / A.n);
+            const int hb = sh.hist_begin;
+            for (long long w = tid; w < (long long)(nh - hb) * A.n; w += RS_T) {
+                const int h = hb + (int)(w / A.n);
                 const int idx = (int)(w % A.n);
                 const int sme = W.hist_slot[h];
                 if (idx == V.p[sme]) continue;
@@ -693,10 +707,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                     rs_add_edge(W, &sh, V.p[sme], idx);
                 }
             }
-            for (long long w = tid; w < (long long)nh * nh; w += RS_T) {
-                const int h = (int)(w / nh), h2 = (int)(w % nh);
+            for (long long w = tid; w < (long long)(nh - hb) * nh; w += RS_T) {
+                const int h = hb + (int)(w / nh), h2 = (int)(w % nh);
                 if (h2 >= h) continue;
                 const int s1 = W.hist_slot[h], s2 = W.hist_slot[h2];
+                if (W.hist_gen[h2] != W.sl_gen[s2]) continue;
                 if (V.label[s1] == V.label[s2]) continue;
                 const double ex = W.hist_x[h2] - W.hist_x[h], ey = W.hist_y[h2] - W.hist_y[h], ez = W.hist_z[h2] - W.hist_z[h];
                 if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, V.p[s1], V.p[s2]);
@@ -712,12 +727,16 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     if (MODE == 1) {
         // the wide commit kernel finishes the sweep
         __syncthreads();
-        if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.ok = ok; sh.dirty = 0; sh.nhist = 0; *ctl = sh; }
+        if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.ok = ok; sh.dirty = 0; *ctl = sh; }
         if (A.dbg && tid == 0) { A.dbg[8] += rounds - 1; A.dbg[12] += 1; }
         return;
     }
-    // ---- commit (MODE 2) -------------------------------------------------------------------------------------------------
+    // ---- commit (monolithic path) ---------------------------------------------------------------------------------------
     const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
+    if (!A.allpairs) {
+        const int nh_all = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+        for (int h = tid; h < nh_all; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
+    }
     for (int s = tid; s < ns; s += RS_T) {
         const int p = V.p[s];
         if (ok && W.sl_moved[s]) {
@@ -728,11 +747,19 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         W.slot_of[p] = -1;
     }
+    if (tid == 0) sh.nhits = 0;
+    __syncthreads();
     if (ok) {
         const int nev = sh.nev < W.max_events ? sh.nev : W.max_events;
-        for (int e = tid; e < nev; e += RS_T)
+        for (int e = tid; e < nev; e += RS_T) {
+            if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;            // event of an emulation that was redone
+            const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];
+            if (owner < A.lo || owner >= A.hi) continue;
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
                      W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
+        }
+        for (int s2 = tid; s2 < ns; s2 += RS_T)
+            if (W.sl_hits[s2]) atomicAdd(&sh.nhits, W.sl_hits[s2]);
     }
     __syncthreads();
     RS_STAMP(5);
@@ -762,7 +789,7 @@ __global__ __launch_bounds__(64) void k_validate(rs_args A)
     const int nh = ctl->nhist < A.W.max_hist ? ctl->nhist : A.W.max_hist;
     const int ns = ctl->nslots0;        // slots that existed when the labels were written
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
-    for (int h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
+    for (int h = ctl->hist_begin + blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
         rs_probe(A, A.G, ctl, A.W.sl_label, ns, A.W.max_slots, h, cr2i);
 }
 
@@ -785,10 +812,12 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
             A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
             A.S.flag[p] = W.sl_flag[s];
         }
+        if (ok && A.count_pp && W.sl_hits[s]) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)W.sl_hits[s]);
         W.slot_of[p] = -1;
     }
     if (ok)
         for (int e = gtid; e < nev; e += gstride) {
+            if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;          // event of an emulation that was redone since
             const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];      // the particle whose free path completed
             if (owner < A.lo || owner >= A.hi) continue;
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
@@ -801,10 +830,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         cnt->n_clusters += (unsigned long long)ctl->nclusters;
         cnt->n_rounds += (unsigned long long)ctl->rounds;
         if (ok) {
-            if (A.count_pp) {
-                cnt->n_pp += (unsigned long long)ctl->nhits;
-                cnt->n_fp_errors += (unsigned long long)ctl->nfp;
-            }
+            if (A.count_pp) cnt->n_fp_errors += (unsigned long long)ctl->nfp;
         } else {
             cnt->flags |= 4ULL;
         }
@@ -874,6 +900,7 @@ static rs_args rs_make_args(amc_ctx *c)
     A.P = c->P; A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
     A.dbg = c->d_dbg;
     A.single_round = 0;
+    A.allow_mono = 1;
     A.count_pp = c->mg_count_pp ? 1 : 0;
     A.lo = c->lo; A.hi = c->hi;
     A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;
@@ -897,6 +924,7 @@ hipError_t amc_launch_resolve(amc_ctx *c)
 template <int GEOM>
 static void rs_launch_round(amc_ctx *c, rs_args A, int first)
 {
+    A.allow_mono = 0;           // the host drives the rounds (state exchange between them)
     if (first) {
         hipLaunchKernelGGL(k_gather_cst, dim3(64), dim3(256), 0, c->stream, A);
         hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);

@@ -8,11 +8,12 @@
 // Legality of the fusion: every wall case and every bounds test reads and writes only the particle itself, and
 // the reference evaluates the cases in a fixed order with each mask computed after the previous handler ran
 // (Pore:442-485) — which is exactly a per-particle sequential evaluation.
-#include "amc_internal.h"
+#include "amc_grid_dev.h"
 
 template <int GEOM>
 __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
-                                                long long lo, long long hi, int keep_prior, int bounds_slot)
+                                                long long lo, long long hi, int keep_prior, int bounds_slot,
+                                                amc_grid G, int *cell_count, int *cid, int *rank)
 {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
@@ -107,13 +108,26 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         if (q.dz != dz_in) S.dz[p] = q.dz;
         if (q.flag != flag_in) S.flag[p] = 1;
     }
+    // fused first pass of the counting sort into the detection grid (amc_grid.hip): the particle's final position of
+    // this stage is in registers, so the separate k_bin_count pass over the positions is saved
+    if (cell_count) {
+        int cx, cy, cz;
+        amc_grid_coords(G, q.x, q.y, q.z, cx, cy, cz);
+        bool outside = false;
+        const int c = amc_grid_cell(G, cx, cy, cz, &outside);
+        if (outside) atomicOr(&O.cnt->flags, 8ULL);
+        cid[p] = c;
+        rank[p] = atomicAdd(&cell_count[c], 1);
+    }
     if (nwall) atomicAdd(&O.cnt->n_wall, (unsigned long long)nwall);
     if (nerr) atomicAdd(&O.cnt->n_fp_errors, (unsigned long long)nerr);
     if (noob) atomicAdd(bounds_slot ? &O.cnt->n_oob_pp : &O.cnt->n_oob_walls, (unsigned long long)noob);
 }
 
-hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot)
+hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin)
 {
+    int *cc = nullptr, *cid = nullptr, *rank = nullptr;
+    if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { cc = c->B.cell_count; cid = c->B.cid; rank = c->B.rank; }
     const long long cnt = c->hi - c->lo;
     if (cnt <= 0) return hipSuccess;
     const int threads = 256;
@@ -123,15 +137,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot)
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
         break;
     case AMC_GEOM_PORE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
         break;
     case AMC_GEOM_PORE_ENERGISED:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
-                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot);
+                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
         break;
     default:
         break;
