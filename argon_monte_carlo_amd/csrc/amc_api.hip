@@ -107,6 +107,8 @@ static int setup_grid(amc_ctx *c)
         h *= 1.26;
     }
     G.h = h;
+    G.inv_h = 1.0 / h;
+    G.uniform = (P.geometry == AMC_GEOM_CUBE) ? 1 : 0;
     G.x0 = xlo - h; G.y0 = xlo - h; G.z0 = zlo - h;           // one guard cell on every side
     G.gx = G.gy = (int)ceil((xhi - xlo) / h) + 2;
     G.gz = (int)ceil((zhi - zlo) / h) + 2;
@@ -157,7 +159,7 @@ void amc_destroy(amc_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
-                    c->S.pz, c->S.flag, c->d_lay, c->B.sx, c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, c->B.cell_count,
+                    c->S.pz, c->S.flag, c->d_lay, c->B.sp, c->B.cell_start, c->B.cell_count,
                     c->B.cid, c->B.rank, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
                     c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
@@ -241,7 +243,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
         if ((rc = setup_grid(c)) != AMC_OK) goto fail;
         if (!c->allpairs) {
             const size_t nc = (size_t)c->G.ncells;
-            CK(dalloc(&c->B.sx, n)); CK(dalloc(&c->B.sy, n)); CK(dalloc(&c->B.sz, n)); CK(dalloc(&c->B.sidx, n));
+            CK(dalloc(&c->B.sp, n));
             CK(dalloc(&c->B.cid, n)); CK(dalloc(&c->B.rank, n));
             CK(dalloc(&c->B.cell_start, nc + 1)); CK(dalloc(&c->B.cell_count, nc + 1));
             c->scan_blocks = (int)((nc + 4095) / 4096);

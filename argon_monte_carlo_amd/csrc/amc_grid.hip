@@ -108,69 +108,101 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_add(int *__restrict__ out, int 
 __global__ __launch_bounds__(256) void k_bin_scatter(const double *__restrict__ x, const double *__restrict__ y,
                                                      const double *__restrict__ z, long long n,
                                                      const int *__restrict__ cid, const int *__restrict__ rank,
-                                                     const int *__restrict__ cell_start, double *__restrict__ sx,
-                                                     double *__restrict__ sy, double *__restrict__ sz,
-                                                     int *__restrict__ sidx)
+                                                     const int *__restrict__ cell_start, double4 *__restrict__ sp)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const int s = cell_start[cid[p]] + rank[p];
-    sx[s] = x[p]; sy[s] = y[p]; sz[s] = z[p];
-    sidx[s] = (int)p;
+    sp[s] = make_double4(x[p], y[p], z[p], amc_sp_pack((int)p));      // one 32-byte scattered store per particle
 }
 
 // ---- binned detection: one thread per sorted particle, half stencil ------------------------------------------------
 // A candidate is stored as (i, j) with i > j plus a copy of both particles' state in a SoA table (cst[e][k], e = 0..10
 // particle j, 11..21 particle i): the single-workgroup resolve kernel then reads coalesced rows instead of issuing
-// 22 scattered loads per pair from one CU.
-AMC_DEV void amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                                const amc_state &S, double *cst)
+// 22 scattered loads per pair from one CU.  Returns the candidate's slot (or -1 on overflow).
+AMC_DEV int amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
 {
     const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
     if (k < (unsigned)max_cand) {
-        const int i = a > b ? a : b, j = a > b ? b : a;
-        cand_i[k] = i;
-        cand_j[k] = j;
-        const size_t m = (size_t)max_cand;
-        const int pp[2] = {j, i};
-#pragma unroll
-        for (int w = 0; w < 2; w++) {
-            const int p = pp[w];
-            double *t = cst + (size_t)(11 * w) * m + k;
-            t[0 * m] = S.x[p]; t[1 * m] = S.y[p]; t[2 * m] = S.z[p];
-            t[3 * m] = S.vx[p]; t[4 * m] = S.vy[p]; t[5 * m] = S.vz[p];
-            t[6 * m] = S.d[p]; t[7 * m] = S.dx[p]; t[8 * m] = S.dy[p]; t[9 * m] = S.dz[p];
-            t[10 * m] = S.flag[p] ? 1.0 : 0.0;
+        cand_i[k] = a > b ? a : b;
+        cand_j[k] = a > b ? b : a;
+        return (int)k;
+    }
+    atomicOr(&cnt->flags, 1ULL);
+    return -1;
+}
+
+// state gather for the candidates found by the lanes of this wave, done by the WHOLE wave: lane e < 22 moves element
+// e of the pair (11 per particle), so a candidate costs one load + one store instruction instead of 44 serial ones
+AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int my_j, int max_cand,
+                             const amc_state &S, double *cst)
+{
+    const int lane = threadIdx.x & 63;
+    while (found) {
+        const int src = __ffsll((long long)found) - 1;
+        found &= found - 1;
+        const int k = __shfl(my_k, src, 64);
+        const int pi = __shfl(my_i, src, 64), pj = __shfl(my_j, src, 64);     // (i > j), straight from the finder's registers
+        if (k < 0 || lane >= 22) continue;
+        const int w = lane / 11, e = lane % 11;
+        const int p = w ? pi : pj;
+        double v;
+        switch (e) {
+        case 0: v = S.x[p]; break; case 1: v = S.y[p]; break; case 2: v = S.z[p]; break;
+        case 3: v = S.vx[p]; break; case 4: v = S.vy[p]; break; case 5: v = S.vz[p]; break;
+        case 6: v = S.d[p]; break; case 7: v = S.dx[p]; break; case 8: v = S.dy[p]; break; case 9: v = S.dz[p]; break;
+        default: v = S.flag[p] ? 1.0 : 0.0; break;
         }
-    } else {
-        atomicOr(&cnt->flags, 1ULL);
+        cst[(size_t)lane * (size_t)max_cand + k] = v;
     }
 }
 
-__global__ __launch_bounds__(256) void k_detect_binned(amc_grid G, const double *__restrict__ sx,
-                                                       const double *__restrict__ sy, const double *__restrict__ sz,
-                                                       const int *__restrict__ sidx,
+__global__ __launch_bounds__(256) void k_detect_binned(amc_grid G, const double4 *__restrict__ sp,
                                                        const int *__restrict__ cell_start, long long n, double cr2i,
-                                                       double cr_probe, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                                                       amc_state S, double *cst)
+                                                       double cr_probe, int *cand_i, int *cand_j, int max_cand,
+                                                       amc_dev_counters *cnt, amc_state S, double *cst)
 {
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const double x = sx[s], y = sy[s], z = sz[s];
-    const int me = sidx[s];
-    // cells overlapped by my collision_range box (1.7 on average, 8 at most); each pair is seen from both ends and
-    // emitted by the one that comes later in the sorted order
-    int cells[8];
-    const int nc = amc_grid_box_cells(G, x, y, z, cr_probe, cells);
-    for (int k = 0; k < nc; k++) {
-        const int q0 = cell_start[cells[k]], q1 = cell_start[cells[k] + 1];
-        for (int q = q0; q < q1; q++) {
-            if (q <= (int)s) continue;
-            const double ex = sx[q] - x, ey = sy[q] - y, ez = sz[q] - z;
-            const double d2 = ex * ex + ey * ey + ez * ez;
-            if (d2 < cr2i) amc_push_candidate(me, sidx[q], cand_i, cand_j, max_cand, cnt, S, cst);
+    int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
+    if (s < n) {
+        const double4 me = sp[s];
+        const int me_idx = amc_sp_index(me);
+        // cells overlapped by my collision_range box (1.7 on average, 8 at most); each pair is seen from both ends
+        // and emitted by the one that comes later in the sorted order
+        int c_lo[4], c_hi[4];
+        const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
+        for (int k = 0; k < nc; k++) {
+            const int q0 = cell_start[c_lo[k]], q1 = cell_start[c_hi[k] + 1];
+            for (int q = q0; q < q1; q++) {
+                if (q <= (int)s) continue;
+                const double4 o = sp[q];
+                const double ex = o.x - me.x, ey = o.y - me.y, ez = o.z - me.z;
+                if (ex * ex + ey * ey + ez * ez < cr2i) {
+                    const int kk = amc_push_candidate(me_idx, amc_sp_index(o), cand_i, cand_j, max_cand, cnt);
+                    if (my_k >= 0 && kk >= 0) {
+                        // second pair of this lane: gather it alone (divergent, rare)
+                        const int oi2 = amc_sp_index(o);
+                        const int hi2 = me_idx > oi2 ? me_idx : oi2, lo2 = me_idx > oi2 ? oi2 : me_idx;
+                        for (int lane = 0; lane < 22; lane++) {
+                            const int p = lane / 11 ? hi2 : lo2;
+                            const int e = lane % 11;
+                            const double v = e == 0 ? S.x[p] : e == 1 ? S.y[p] : e == 2 ? S.z[p] : e == 3 ? S.vx[p] :
+                                             e == 4 ? S.vy[p] : e == 5 ? S.vz[p] : e == 6 ? S.d[p] : e == 7 ? S.dx[p] :
+                                             e == 8 ? S.dy[p] : e == 9 ? S.dz[p] : (S.flag[p] ? 1.0 : 0.0);
+                            cst[(size_t)lane * (size_t)max_cand + kk] = v;
+                        }
+                    } else {
+                        my_k = kk;
+                        const int oi = amc_sp_index(o);
+                        my_i = me_idx > oi ? me_idx : oi;
+                        my_j = me_idx > oi ? oi : me_idx;
+                    }
+                }
+            }
         }
     }
+    const unsigned long long found = __ballot(my_k >= 0);
+    if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);
 }
 
 // ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
@@ -202,7 +234,18 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
     for (int k = 0; k < jmax; k++) {
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
         const double d2 = ex * ex + ey * ey + ez * ez;
-        if (d2 < cr2i) amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt, S, cst);
+        if (d2 < cr2i) {
+            const int kk = amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt);
+            if (kk >= 0)
+                for (int lane = 0; lane < 22; lane++) {
+                    const int p = lane / 11 ? i : (j0 + k);
+                    const int e = lane % 11;
+                    const double v = e == 0 ? S.x[p] : e == 1 ? S.y[p] : e == 2 ? S.z[p] : e == 3 ? S.vx[p] : e == 4 ? S.vy[p] :
+                                     e == 5 ? S.vz[p] : e == 6 ? S.d[p] : e == 7 ? S.dx[p] : e == 8 ? S.dy[p] : e == 9 ? S.dz[p] :
+                                     (S.flag[p] ? 1.0 : 0.0);
+                    cst[(size_t)lane * (size_t)max_cand + kk] = v;
+                }
+        }
     }
 }
 
@@ -235,7 +278,7 @@ hipError_t amc_launch_bin(amc_ctx *c, bool counted)
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_BIN_SCATTER);
     hipLaunchKernelGGL(k_bin_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z,
-                       n, c->B.cid, c->B.rank, c->B.cell_start, c->B.sx, c->B.sy, c->B.sz, c->B.sidx);
+                       n, c->B.cid, c->B.rank, c->B.cell_start, c->B.sp);
     amc_prof_end(c);
     return hipGetLastError();
 }
@@ -252,8 +295,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
             hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
                                c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst);
     } else {
-        hipLaunchKernelGGL(k_detect_binned, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B.sx,
-                           c->B.sy, c->B.sz, c->B.sidx, c->B.cell_start, n, cr2i, c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j,
+        hipLaunchKernelGGL(k_detect_binned, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B.sp, c->B.cell_start, n, cr2i, c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j,
                            c->W.max_cand, c->d_cnt, c->S, c->W.cst);
     }
     amc_prof_end(c);

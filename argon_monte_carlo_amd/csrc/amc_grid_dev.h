@@ -6,15 +6,16 @@ AMC_DEV int amc_clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? h
 
 AMC_DEV void amc_grid_coords(const amc_grid &G, double x, double y, double z, int &cx, int &cy, int &cz)
 {
-    cx = amc_clampi((int)floor((x - G.x0) / G.h), 0, G.gx - 1);
-    cy = amc_clampi((int)floor((y - G.y0) / G.h), 0, G.gy - 1);
-    cz = amc_clampi((int)floor((z - G.z0) / G.h), 0, G.gz - 1);
+    cx = amc_clampi((int)floor((x - G.x0) * G.inv_h), 0, G.gx - 1);
+    cy = amc_clampi((int)floor((y - G.y0) * G.inv_h), 0, G.gy - 1);
+    cz = amc_clampi((int)floor((z - G.z0) * G.inv_h), 0, G.gz - 1);
 }
 
 // linear id of the cell that STORES a particle with coordinates (cx,cy,cz): coordinates outside the layer's window
 // are clamped into it (cannot happen for in-bounds particles; *outside is set so the caller can flag it)
 AMC_DEV int amc_grid_cell(const amc_grid &G, int cx, int cy, int cz, bool *outside)
 {
+    if (G.uniform) return (cz * G.gy + cy) * G.gx + cx;      // coordinates are already clamped into the full window
     const int lo = G.lay_lo[cz], n = G.lay_n[cz];
     int lx = cx - lo, ly = cy - lo;
     if (lx < 0 || lx >= n || ly < 0 || ly >= n) {
@@ -44,22 +45,38 @@ AMC_DEV bool amc_grid_row(const amc_grid &G, int cx, int cy, int cz, int &c_lo, 
     return true;
 }
 
-// The stored cells that can hold a particle within distance r of (x,y,z): the cells overlapped by the box
-// [x-r,x+r] x [y-r,y+r] x [z-r,z+r] — at most 2 per axis because h >= r — after the same monotone clamps that
-// amc_grid_coords / amc_grid_cell apply to particles.  Writes up to 8 distinct cell ids, returns their number.
-AMC_DEV int amc_grid_box_cells(const amc_grid &G, double x, double y, double z, double r, int *cells)
+// The stored cells that can hold a particle within distance r (<= h/2) of (x,y,z), as up to four runs of x-adjacent
+// cells [c_lo, c_hi] (contiguous in the sorted arrays).  One floor per axis: with f = fractional position inside the
+// cell, the lower neighbour is needed iff f < r/h and the upper one iff f > 1 - r/h; the thresholds are inflated by
+// 1e-6 cells, far above the rounding of (v - v0) * inv_h (~1e-13 cells), so the set is a superset of the exact one
+// under the same monotone clamps that binning applies.  Returns the number of runs.
+AMC_DEV int amc_grid_box_ranges(const amc_grid &G, double x, double y, double z, double r, int *c_lo, int *c_hi)
 {
-    int x0, y0, z0, x1, y1, z1;
-    amc_grid_coords(G, x - r, y - r, z - r, x0, y0, z0);
-    amc_grid_coords(G, x + r, y + r, z + r, x1, y1, z1);
+    const double ux = (x - G.x0) * G.inv_h, uy = (y - G.y0) * G.inv_h, uz = (z - G.z0) * G.inv_h;
+    const double fx0 = floor(ux), fy0 = floor(uy), fz0 = floor(uz);
+    const double t = r * G.inv_h + 1.0e-6;
+    const int cx = amc_clampi((int)fx0, 0, G.gx - 1), cy = amc_clampi((int)fy0, 0, G.gy - 1), cz = amc_clampi((int)fz0, 0, G.gz - 1);
+    const double fx = ux - fx0, fy = uy - fy0, fz = uz - fz0;
+    // coordinates outside the grid are clamped by binning; there the fractional test is meaningless -> take both sides
+    const bool ox = (fx0 < 0) || (fx0 > G.gx - 1), oy = (fy0 < 0) || (fy0 > G.gy - 1), oz = (fz0 < 0) || (fz0 > G.gz - 1);
+    const int x_lo = amc_clampi(cx - ((fx < t || ox) ? 1 : 0), 0, G.gx - 1), x_hi = amc_clampi(cx + ((fx > 1.0 - t || ox) ? 1 : 0), 0, G.gx - 1);
+    const int y_lo = amc_clampi(cy - ((fy < t || oy) ? 1 : 0), 0, G.gy - 1), y_hi = amc_clampi(cy + ((fy > 1.0 - t || oy) ? 1 : 0), 0, G.gy - 1);
+    const int z_lo = amc_clampi(cz - ((fz < t || oz) ? 1 : 0), 0, G.gz - 1), z_hi = amc_clampi(cz + ((fz > 1.0 - t || oz) ? 1 : 0), 0, G.gz - 1);
     int n = 0;
-    for (int cz = z0; cz <= z1; cz++)
-        for (int cy = y0; cy <= y1; cy++)
-            for (int cx = x0; cx <= x1; cx++) {
-                const int c = amc_grid_cell(G, cx, cy, cz, nullptr);
-                bool dup = false;
-                for (int k = 0; k < n; k++) dup |= (cells[k] == c);
-                if (!dup && n < 8) cells[n++] = c;
-            }
+    for (int kz = z_lo; kz <= z_hi; kz++) {
+        int lo = 0, nn = G.gx, off;
+        if (G.uniform) off = kz * G.gy * G.gx;
+        else { lo = G.lay_lo[kz]; nn = G.lay_n[kz]; off = G.lay_off[kz]; }
+        // window clamp of this layer (binning clamps out-of-window particles into the edge cells)
+        const int a = amc_clampi(x_lo - lo, 0, nn - 1), b = amc_clampi(x_hi - lo, 0, nn - 1);
+        const int ya = amc_clampi(y_lo - lo, 0, nn - 1), yb = amc_clampi(y_hi - lo, 0, nn - 1);
+        for (int ky = ya; ky <= yb; ky++) {
+            if (n < 4) { c_lo[n] = off + ky * nn + a; c_hi[n] = off + ky * nn + b; n++; }
+        }
+    }
     return n;
 }
+
+// particle index stored in the 4th lane of a sorted record
+AMC_DEV int amc_sp_index(const double4 &r) { return (int)__double_as_longlong(r.w); }
+AMC_DEV double amc_sp_pack(int idx) { return __longlong_as_double((long long)idx); }

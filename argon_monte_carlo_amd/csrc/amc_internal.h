@@ -19,6 +19,9 @@ struct amc_state {
 // (the pore's body is 68 nm wide inside a 300 nm bounding box: a dense grid would be ~12x larger than needed)
 struct amc_grid {
     double x0, y0, z0, h;
+    double inv_h;             // cell coordinate = floor((v - v0) * inv_h): any monotone map works as long as binning
+                              // and probing use the same one
+    int uniform;              // 1: every layer stores the full gx*gy window (cube) -> no table lookups
     int gx, gy, gz;           // global extent in cells
     int ncells;               // stored cells = sum over layers of lay_n^2  (0 = no grid: all-pairs mode)
     const int *lay_lo;        // [gz] first stored cell coordinate of the window (same for x and y)
@@ -27,8 +30,7 @@ struct amc_grid {
 };
 
 struct amc_sorted {
-    double *sx, *sy, *sz;     // positions in cell order (x fastest, then y, then z layer)
-    int *sidx;                // particle index of each sorted entry
+    double4 *sp;              // cell-ordered copy, ONE 32-byte record per particle: x, y, z, particle index (as bits)
     int *cell_start;          // [ncells+1] exclusive prefix of the per-cell counts
     int *cell_count;          // [ncells]
     int *cid, *rank;          // [n] cell id and arrival rank of each particle

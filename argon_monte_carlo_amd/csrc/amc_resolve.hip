@@ -422,12 +422,16 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
     // only the cells overlapped by the collision_range box around the new position can hold a partner (1.7 cells on
     // average): fetch their bounds and overlay heads first, then the entries in batches
-    int cells[8], q0[8], q1[8], ovh[8];
-    const int ncell = amc_grid_box_cells(G, x, y, z, A.P.collision_range * 1.000001, cells);
+    int c_lo[4], c_hi[4], q0[4], q1[4], ovh[8];
+    const int ncell = amc_grid_box_ranges(G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        q0[k] = q1[k] = 0; ovh[k] = -1;
-        if (k < ncell) { q0[k] = A.B.cell_start[cells[k]]; q1[k] = A.B.cell_start[cells[k] + 1]; ovh[k] = W.ov_head[cells[k]]; }
+    for (int k = 0; k < 4; k++) {
+        q0[k] = q1[k] = 0; ovh[2 * k] = ovh[2 * k + 1] = -1;
+        if (k < ncell) {
+            q0[k] = A.B.cell_start[c_lo[k]]; q1[k] = A.B.cell_start[c_hi[k] + 1];
+            ovh[2 * k] = W.ov_head[c_lo[k]];
+            if (c_hi[k] != c_lo[k]) ovh[2 * k + 1] = W.ov_head[c_hi[k]];
+        }
     }
     int bq[RS_VAL_BATCH];
     int nb = 0;
@@ -436,7 +440,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         int bi[RS_VAL_BATCH];
 #pragma unroll
         for (int k = 0; k < RS_VAL_BATCH; k++)
-            if (k < nb) { ex[k] = A.B.sx[bq[k]]; ey[k] = A.B.sy[bq[k]]; ez[k] = A.B.sz[bq[k]]; bi[k] = A.B.sidx[bq[k]]; }
+            if (k < nb) { const double4 r = A.B.sp[bq[k]]; ex[k] = r.x; ey[k] = r.y; ez[k] = r.z; bi[k] = amc_sp_index(r); }
 #pragma unroll
         for (int k = 0; k < RS_VAL_BATCH; k++) {
             if (k >= nb) continue;
@@ -459,7 +463,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         }
     if (nb) flush();
     // new positions of other clusters' members (overlay lists of the same cells)
-    for (int k = 0; k < ncell; k++)
+    for (int k = 0; k < 2 * ncell; k++)
         for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
             if (h2 == h) continue;
             const int s2 = W.hist_slot[h2];
