@@ -246,6 +246,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
             CK(dalloc(&c->B.sp, n));
             CK(dalloc(&c->B.cid, n)); CK(dalloc(&c->B.rank, n));
             CK(dalloc(&c->B.cell_start, nc + 1)); CK(dalloc(&c->B.cell_count, nc + 1));
+            CK(hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (nc + 1), c->stream));
             c->scan_blocks = (int)((nc + 4095) / 4096);
             CK(dalloc(&c->scan_tmp, (size_t)c->scan_blocks + 1));
             CK(dalloc(&c->W.ov_head, nc));

@@ -66,7 +66,8 @@ __device__ inline int block_exclusive_scan_1024(int v, int *total)
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_T) void k_scan_block(const int *__restrict__ in, int *__restrict__ out, int n,
+// reads the per-cell counts AND zeroes them for the next step's counting pass (saves a memset launch per step)
+__global__ __launch_bounds__(SCAN_T) void k_scan_block(int *__restrict__ in, int *__restrict__ out, int n,
                                                        int *__restrict__ block_sums)
 {
     const int base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_block(const int *__restrict__ i
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         v[k] = (base + k < n) ? in[base + k] : 0;
+        if (base + k < n) in[base + k] = 0;
         s += v[k];
     }
     int total;
@@ -252,8 +254,9 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
 // ---- launchers ---------------------------------------------------------------------------------------------------
 hipError_t amc_launch_bin_clear(amc_ctx *c)
 {
-    if (c->allpairs) return hipSuccess;
-    return hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (size_t)c->G.ncells, c->stream);
+    // the counters are zeroed once at creation and re-zeroed by k_scan_block every time they are consumed
+    (void)c;
+    return hipSuccess;
 }
 
 hipError_t amc_launch_bin(amc_ctx *c, bool counted)

@@ -490,7 +490,7 @@ AMC_DEV int rs_hist_cell(const rs_args &A, const amc_grid &G, int h)
         }                                                                                  \
     } while (0)
 
-#define RS_NS 2048             // slot labels / sizes kept in LDS
+#define RS_NS 6144             // slot labels / sizes / dirty flags kept in LDS (54 KB)
 #define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
 #define RS_SMALL 640           // candidate pairs up to which resolve_A does everything itself
 
