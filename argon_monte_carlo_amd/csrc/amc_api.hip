@@ -213,6 +213,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
     c->mg_count_pp = true;
+    c->mg_ncand = 0;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
     c->stream = nullptr;
     int rc = AMC_OK;
@@ -821,6 +822,7 @@ int amc_mg_detect(amc_ctx *c, int64_t *n_candidates)
     if (rc) return rc;
     if (now.cand_count > (unsigned)c->W.max_cand) return amc_fail(c, AMC_ERR_CAPACITY, "candidate list overflow (%u)", now.cand_count);
     if (n_candidates) *n_candidates = now.cand_count;
+    c->mg_ncand = (int)now.cand_count;
     return AMC_OK;
 }
 
@@ -828,10 +830,7 @@ int amc_mg_candidates(amc_ctx *c, int32_t *cand_i, int32_t *cand_j, size_t cap, 
 {
     if (!c || !n) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
-    amc_dev_counters now;
-    int rc = read_counters(c, &now);
-    if (rc) return rc;
-    const size_t k = std::min<size_t>(now.cand_count, (size_t)c->W.max_cand);
+    const size_t k = std::min<size_t>((size_t)std::max(c->mg_ncand, 0), (size_t)c->W.max_cand);   // from amc_mg_detect
     if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "amc_mg_candidates: %zu pairs, buffer holds %zu", k, cap);
     if (k) {
         AMC_HIP(c, hipMemcpyAsync(cand_i, c->W.cand_i, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream));
@@ -907,6 +906,7 @@ int amc_mg_finish(amc_ctx *c, amc_step_stats *out)
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->P.geometry == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));
     c->out.step++;
+    if (!out) return AMC_OK;        // asynchronous: the caller reads the counters later
     return finish_stats(c, out);
 }
 

@@ -115,6 +115,7 @@ struct amc_ctx {
     void *xchg_send, *xchg_recv;   // xchg_send = state table float64[11][n_list]; xchg_recv = int32 particle list
     int64_t xchg_stride;           // capacity of both, in particles
     bool mg_count_pp;              // this rank adds the p-p collision count to its counters
+    int mg_ncand;                  // candidate count read back by the last amc_mg_detect
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);

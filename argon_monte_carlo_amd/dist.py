@@ -30,15 +30,19 @@ class TorchComm:
 
     def __init__(self, rank, world, group=None):
         import torch.distributed as dist
+        import os
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
-        self.backend = dist.get_backend(group) if world > 1 else "none"
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        # world == 1 normally skips the collectives; AMC_DIST_NOSHORTCUT=1 issues them anyway (single-GPU rehearsal
+        # of the RCCL code path: tensor aliasing, in-place all-gather, int64 all-reduce)
+        self.shortcut = not (os.environ.get("AMC_DIST_NOSHORTCUT") == "1" and dist.is_initialized())
 
     def _stage(self, t):
         return t.is_cuda and self.backend != "nccl"
 
     def allgather_inplace(self, full, n, world):
         """full[lo:hi] of every rank -> full on every rank."""
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return
         import torch
         ranges = [shard_range(n, r, world) for r in range(world)]
@@ -67,7 +71,7 @@ class TorchComm:
         return [p[:b - a].cpu() for (a, b), p in zip(ranges, parts)]
 
     def allreduce_bits(self, t):
-        if self.world == 1 or t.numel() == 0:
+        if (self.world == 1 and self.shortcut) or t.numel() == 0:
             return
         if self._stage(t):
             h = t.cpu()
@@ -78,7 +82,7 @@ class TorchComm:
 
     def allreduce_sum_ints(self, values):
         import torch
-        if self.world == 1:
+        if self.world == 1 and self.shortcut:
             return list(values)
         t = torch.tensor(list(values), dtype=torch.int64)
         if self.backend == "nccl":
@@ -124,7 +128,7 @@ class ShardedSimulation:
         self.comm.allreduce_bits(self.engine.exchange_tensor(len(particles)))
         self.engine.mg_unpack(particles)
 
-    def timestep(self, dt, reduce_stats=True):
+    def timestep(self, dt, reduce_stats=True, want_stats=True):
         e = self.engine
         e.mg_local(dt)
         for t in e.position_tensors():
@@ -144,18 +148,23 @@ class ShardedSimulation:
                 dirty, new = e.mg_resolve_round(False)
                 rounds += 1
             e.mg_commit()
-        st = e.mg_finish()
+        st = e.mg_finish(want_stats)
+        if st is None:
+            return None
         st["n_rounds"] = rounds
-        if reduce_stats and self.world > 1:
+        if reduce_stats and (self.world > 1 or not getattr(self.comm, 'shortcut', True)):
             tot = self.comm.allreduce_sum_ints([st[k] for k in self.SUM_KEYS])
             st.update(dict(zip(self.SUM_KEYS, tot)))
         return st
 
     def run(self, dt, nsteps):
         acc = None
-        for _ in range(int(nsteps)):
-            st = self.timestep(dt, reduce_stats=False)
-            acc = st if acc is None else {k: acc[k] + st[k] for k in st}
+        nsteps = int(nsteps)
+        for k in range(nsteps):
+            # counters are cumulative on the device: only the last step reads them back (deltas since the last read)
+            st = self.timestep(dt, reduce_stats=False, want_stats=(k == nsteps - 1))
+            if st is not None:
+                acc = st
         if acc is not None and self.world > 1:
             tot = self.comm.allreduce_sum_ints([acc[k] for k in self.SUM_KEYS])
             acc.update(dict(zip(self.SUM_KEYS, tot)))

@@ -186,12 +186,16 @@ class ShardEngine(Engine):
         return torch.as_tensor(d, device="cuda")
 
     def position_tensors(self):
-        v = self._view
-        return [self._wrap(p, self.n, "<f8") for p in (v.x, v.y, v.z)]
+        if not hasattr(self, "_pos_t"):
+            v = self._view
+            self._pos_t = [self._wrap(p, self.n, "<f8") for p in (v.x, v.y, v.z)]
+        return self._pos_t
 
     def exchange_tensor(self, n_particles):
         """int64 view of the state table rows in use: [11 * n_particles]."""
-        return self._wrap(self._view.xchg, 11 * int(n_particles), "<i8")
+        if not hasattr(self, "_xchg_t"):
+            self._xchg_t = self._wrap(self._view.xchg, 11 * int(self._view.xchg_capacity), "<i8")
+        return self._xchg_t[: 11 * int(n_particles)]
 
     def mg_local(self, dt):
         self._ck(self.lib.amc_mg_local(self._ctx, float(dt)))
@@ -226,7 +230,10 @@ class ShardEngine(Engine):
     def mg_commit(self):
         self._ck(self.lib.amc_mg_commit(self._ctx))
 
-    def mg_finish(self):
+    def mg_finish(self, want_stats=True):
+        if not want_stats:
+            self._ck(self.lib.amc_mg_finish(self._ctx, None))
+            return None
         st = AmcStepStats()
         self._ck(self.lib.amc_mg_finish(self._ctx, C.byref(st)))
         return st.as_dict()

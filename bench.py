@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
+    ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +98,13 @@ def main():
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.force_sharded:
+            os.environ["AMC_DIST_NOSHORTCUT"] = "1"
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -111,7 +117,7 @@ def main():
         n_per_gpu = args.n
     stream_ptr = torch.cuda.current_stream().cuda_stream
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
         eng = Engine(p)
         eng.set_stream(stream_ptr)
@@ -183,7 +189,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

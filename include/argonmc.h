@@ -253,7 +253,7 @@ int amc_mg_unpack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
  * (another round is needed); new_members receives the particles pulled in by validation (ascending). */
 int amc_mg_resolve_round(amc_ctx *ctx, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new);
 int amc_mg_commit(amc_ctx *ctx);
-int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);
+int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no host synchronisation (counters stay on the device) */
 
 /* ---- measurement ----------------------------------------------------------------------------------------- */
 /* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */

@@ -119,7 +119,7 @@ class NumpyShardEngine:
             for k in ("vx", "vy", "vz"):
                 self.a[k][p] = self.vnew[k][p]
 
-    def mg_finish(self):
+    def mg_finish(self, want_stats=True):
         return dict(n_pp=len(self.cand[0]) if self.lo == 0 else 0, n_wall=self.hi - self.lo, n_oob_walls=0, n_oob_pp=0,
                     n_paths=0, n_candidates=len(self.cand[0]), n_clusters=0, n_rounds=self.round, n_fp_errors=0, flags=0)
 
