@@ -81,4 +81,5 @@ def path_record_dtype():
                      ("pz", "<f8")])
 
 
-AMC_K_NAMES = ["drift_walls", "bin_count", "bin_scan", "bin_scatter", "detect", "resolve", "bounds", "other"]
+AMC_K_NAMES = ["drift_walls", "bin_count", "bin_scan", "bin_scatter", "detect", "resolve", "bounds", "validate",
+               "resolve_more", "commit", "other10", "other11"]

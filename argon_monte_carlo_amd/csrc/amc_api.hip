@@ -140,6 +140,8 @@ static int setup_grid(amc_ctx *c)
     return AMC_OK;
 }
 
+static int amc_flush(amc_ctx *c);
+
 extern "C" {
 
 int amc_abi_version(void) { return AMC_ABI_VERSION; }
@@ -148,8 +150,8 @@ const char *amc_last_error(const amc_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 const char *amc_kernel_name(int k)
 {
-    static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan", "bin_scatter",
-                                             "detect",      "resolve",   "bounds",   "other"};
+    static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan",     "bin_scatter", "detect",  "resolve",
+                                             "bounds",      "validate",  "resolve_more", "commit",      "other10", "other11"};
     return (k >= 0 && k < AMC_K_COUNT) ? names[k] : "?";
 }
 
@@ -213,6 +215,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
     c->mg_count_pp = true;
+    c->lazy_pending = false;
     c->mg_ncand = 0;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
     c->stream = nullptr;
@@ -356,6 +359,7 @@ int amc_upload(amc_ctx *c, const double *x, const double *y, const double *z, co
 {
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     const size_t nb = sizeof(double) * (size_t)c->n;
     const double *src[] = {x, y, z, vx, vy, vz, dist, dist_x, dist_y, dist_z};
     double *dst[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz};
@@ -372,6 +376,7 @@ int amc_download(amc_ctx *c, double *x, double *y, double *z, double *vx, double
 {
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     const size_t nb = sizeof(double) * (size_t)c->n;
     double *dst[] = {x, y, z, vx, vy, vz, dist, dist_x, dist_y, dist_z};
     double *src[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz};
@@ -440,11 +445,21 @@ static int finish_stats(amc_ctx *c, amc_step_stats *out)
     return AMC_OK;
 }
 
-static int enqueue_sweep(amc_ctx *c, bool counted = false)
+// sweep results deferred to the next streaming pass: write them now (before anything else reads the particle arrays)
+static int amc_flush(amc_ctx *c)
+{
+    if (!c->lazy_pending) return AMC_OK;
+    AMC_HIP(c, amc_launch_apply(c));
+    c->lazy_pending = false;
+    return AMC_OK;
+}
+
+static int enqueue_sweep(amc_ctx *c, bool counted = false, bool defer_commit = false)
 {
     AMC_HIP(c, amc_launch_bin(c, counted));
     AMC_HIP(c, amc_launch_detect(c));
-    AMC_HIP(c, amc_launch_resolve(c));
+    AMC_HIP(c, amc_launch_resolve(c, defer_commit));
+    if (defer_commit) c->lazy_pending = true;
     return AMC_OK;
 }
 
@@ -461,7 +476,9 @@ static int enqueue_step(amc_ctx *c, double dt)
         if (fuse) AMC_HIP(c, amc_launch_bin_clear(c));
         const int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
         AMC_HIP(c, amc_launch_stream(c, dt, st, 0, fuse));
-        if ((rc = enqueue_sweep(c, fuse))) return rc;
+        // the scattered commit is deferred: the next streaming pass over all particles (the bounds check for the pore,
+        // the next step's drift for the cube) picks the results up through slot_of[]
+        if ((rc = enqueue_sweep(c, fuse, c->lo == 0 && c->hi == c->n))) return rc;
         if (g == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
     } else {
         return amc_fail(c, AMC_ERR_INVALID, "energised walls need the host handshake: use the Python driver (amc_wall_hits/apply)");
@@ -496,6 +513,7 @@ int amc_stage_drift(amc_ctx *c, double dt)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     const bool kp = c->keep_prior;
     c->keep_prior = true;       // a following amc_stage_walls needs prior_*_vals
     hipError_t e = amc_launch_stream(c, dt, AMC_ST_DRIFT, 0);
@@ -509,6 +527,7 @@ int amc_stage_walls(amc_ctx *c, amc_step_stats *out)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_WALLS, 0));
     return finish_stats(c, out);
 }
@@ -517,6 +536,7 @@ int amc_stage_bounds(amc_ctx *c, int64_t *n_moved)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));
     amc_step_stats st;
     int rc = finish_stats(c, &st);
@@ -528,6 +548,7 @@ int amc_stage_sweep(amc_ctx *c, amc_step_stats *out)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     int rc = enqueue_sweep(c);
     if (rc) return rc;
     return finish_stats(c, out);
@@ -689,6 +710,7 @@ int amc_temp_begin(amc_ctx *c, double dt)
     AMC_HIP(c, hipSetDevice(c->device));
     int rc = temp_ensure(c);
     if (rc) return rc;
+    if ((rc = amc_flush(c))) return rc;
     c->keep_prior = true;       // the energised masks read prior_*_vals (Temp:708-750)
     AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
     return AMC_OK;
@@ -803,6 +825,7 @@ int amc_device_view_get(amc_ctx *c, amc_device_view *out)
 int amc_mg_local(amc_ctx *c, double dt)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     if (c->allpairs || c->P.geometry == AMC_GEOM_CELL || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
         return amc_fail(c, AMC_ERR_INVALID, "multi-GPU needs the binned detector and the cube / specular pore geometry");
     AMC_HIP(c, hipSetDevice(c->device));

@@ -36,6 +36,15 @@ struct amc_sorted {
     int *cid, *rank;          // [n] cell id and arrival rank of each particle
 };
 
+// results of the last sweep that have not been written to the particle arrays yet: the next streaming pass picks them
+// up (a coalesced slot_of[] read per particle) instead of a scattered commit from one workgroup
+struct amc_lazy {
+    int *slot_of;
+    const double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
+    const uint8_t *flag, *moved;
+    int enabled;
+};
+
 // ---- resolve scratch ---------------------------------------------------------------------------------------------
 struct amc_resolve_ws {
     int *cand_i, *cand_j;     // candidate pairs, i > j (particle indices)
@@ -115,6 +124,7 @@ struct amc_ctx {
     void *xchg_send, *xchg_recv;   // xchg_send = state table float64[11][n_list]; xchg_recv = int32 particle list
     int64_t xchg_stride;           // capacity of both, in particles
     bool mg_count_pp;              // this rank adds the p-p collision count to its counters
+    bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     int mg_ncand;                  // candidate count read back by the last amc_mg_detect
 };
 
@@ -141,7 +151,8 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
 hipError_t amc_launch_bin_clear(amc_ctx *c);           // zero the per-cell counters (before a fused-count stream pass)
 hipError_t amc_launch_bin(amc_ctx *c, bool counted = false);   // [count +] scan + scatter over all n particles
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
-hipError_t amc_launch_resolve(amc_ctx *c);              // resolve_A -> validate -> resolve_B -> commit
+hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit
+hipError_t amc_launch_apply(amc_ctx *c);                // write deferred sweep results to the particle arrays now
 hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
 hipError_t amc_launch_commit(amc_ctx *c);
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
@@ -151,5 +162,5 @@ hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, 
 struct amc_resolve_ctl {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
     int rounds, ncand, active, ok, edges_done;
-    int nslots0, hist_begin, cur_round;
+    int lazy_ns, nslots0, hist_begin, cur_round;
 };

@@ -43,6 +43,8 @@ struct rs_args {
     long long n;
     int allpairs;
     int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
+    int defer_commit;         // leave the results in the slot arrays: the next streaming pass (or k_apply) writes them
+    int apply_only;           // k_commit: only write deferred results (amc_flush)
     int allow_mono;           // small sweeps may run validation + commit inside resolve_A (saves three kernels' latency)
     int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
@@ -54,6 +56,7 @@ struct rs_args {
 struct rs_shared {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
     int rounds, ncand, active, ok, edges_done;
+    int lazy_ns;              // slots whose results are still only in the slot arrays (deferred commit)
     int nslots0;              // slots that existed (and have labels in W.sl_label) when a resolve kernel handed over
     int hist_begin;           // first history entry of the current round (older ones were validated already)
     int cur_round;
@@ -741,7 +744,8 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         const int nh_all = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
         for (int h = tid; h < nh_all; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
     }
-    for (int s = tid; s < ns; s += RS_T) {
+    const bool defer = ok && A.defer_commit;        // the next streaming pass reads the slot arrays through slot_of[]
+    for (int s = tid; s < ns && !defer; s += RS_T) {
         const int p = V.p[s];
         if (ok && W.sl_moved[s]) {
             A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
@@ -779,6 +783,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             cnt->flags |= 4ULL;
         }
         sh.active = 0;
+        sh.lazy_ns = defer ? ns : 0;
         *ctl = sh;
     }
 }
@@ -801,22 +806,40 @@ __global__ __launch_bounds__(64) void k_validate(rs_args A)
 __global__ __launch_bounds__(256) void k_commit(rs_args A)
 {
     const amc_resolve_ws &W = A.W;
-    const rs_shared *ctl = (const rs_shared *)W.ctl;
+    rs_shared *ctl = (rs_shared *)W.ctl;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    if (A.apply_only) {
+        // amc_flush: deferred results -> particle arrays (single block; the host clears its pending flag)
+        const int ns = ctl->lazy_ns < W.max_slots ? ctl->lazy_ns : W.max_slots;
+        for (int s = gtid; s < ns; s += gstride) {
+            const int p = W.sl_p[s];
+            if (W.slot_of[p] != s) continue;            // consumed by a streaming pass already
+            if (W.sl_moved[s]) {
+                A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
+                A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
+                A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
+                A.S.flag[p] = W.sl_flag[s];
+            }
+            W.slot_of[p] = -1;
+        }
+        return;
+    }
     if (!ctl->active) return;
     const bool ok = ctl->ok && !ctl->ovf;
+    const bool defer = ok && A.defer_commit;
     const int ns = ctl->nslots < W.max_slots ? ctl->nslots : W.max_slots;
     const int nev = ctl->nev < W.max_events ? ctl->nev : W.max_events;
     const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
     for (int s = gtid; s < ns; s += gstride) {
         const int p = W.sl_p[s];
+        if (ok && A.count_pp && W.sl_hits[s]) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)W.sl_hits[s]);
+        if (defer) continue;
         if (ok && W.sl_moved[s]) {
             A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
             A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
             A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
             A.S.flag[p] = W.sl_flag[s];
         }
-        if (ok && A.count_pp && W.sl_hits[s]) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)W.sl_hits[s]);
         W.slot_of[p] = -1;
     }
     if (ok)
@@ -827,7 +850,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
                      W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
         }
-    for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // first-round overlay, if still set
+    for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // overlay entries of this sweep
     if (gtid == 0) {
         amc_dev_counters *cnt = A.O.cnt;
         cnt->n_candidates += (unsigned long long)ctl->ncand;
@@ -838,6 +861,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         } else {
             cnt->flags |= 4ULL;
         }
+        ctl->lazy_ns = defer ? ns : 0;
     }
 }
 
@@ -893,8 +917,14 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
         return;
     }
     hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_VALIDATE);
     hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_RESOLVE_MORE);
     hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_COMMIT);
     hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
 }
 
@@ -905,15 +935,26 @@ static rs_args rs_make_args(amc_ctx *c)
     A.dbg = c->d_dbg;
     A.single_round = 0;
     A.allow_mono = 1;
+    A.defer_commit = 0;
+    A.apply_only = 0;
     A.count_pp = c->mg_count_pp ? 1 : 0;
     A.lo = c->lo; A.hi = c->hi;
     A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;
     return A;
 }
 
-hipError_t amc_launch_resolve(amc_ctx *c)
+hipError_t amc_launch_apply(amc_ctx *c)
 {
-    const rs_args A = rs_make_args(c);
+    rs_args A = rs_make_args(c);
+    A.apply_only = 1;
+    hipLaunchKernelGGL(k_commit, dim3(8), dim3(256), 0, c->stream, A);
+    return hipGetLastError();
+}
+
+hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit)
+{
+    rs_args A = rs_make_args(c);
+    A.defer_commit = defer_commit ? 1 : 0;
     amc_prof_begin(c, AMC_K_RESOLVE);
     switch (c->P.geometry) {
     case AMC_GEOM_CELL: rs_launch_all<AMC_GEOM_CELL>(c, A); break;

@@ -8,12 +8,14 @@
 // Legality of the fusion: every wall case and every bounds test reads and writes only the particle itself, and
 // the reference evaluates the cases in a fixed order with each mask computed after the previous handler ran
 // (Pore:442-485) — which is exactly a per-particle sequential evaluation.
+#include <string.h>
+
 #include "amc_grid_dev.h"
 
 template <int GEOM>
 __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
                                                 long long lo, long long hi, int keep_prior, int bounds_slot,
-                                                amc_grid G, int *cell_count, int *cid, int *rank)
+                                                amc_grid G, int *cell_count, int *cid, int *rank, amc_lazy L)
 {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
@@ -29,7 +31,21 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         q.flag = S.flag[p] != 0;
         flag_in = q.flag; d_in = q.d; dx_in = q.dx; dy_in = q.dy; dz_in = q.dz;
     }
+    // deferred commit of the previous sweep: a particle that collided has its new state in the slot arrays
+    bool force = false;
+    if (L.enabled) {
+        const int sl = L.slot_of[p];
+        if (sl >= 0) {
+            L.slot_of[p] = -1;
+            if (L.moved[sl]) {
+                q.x = L.x[sl]; q.y = L.y[sl]; q.z = L.z[sl]; q.vx = L.vx[sl]; q.vy = L.vy[sl]; q.vz = L.vz[sl];
+                q.d = L.d[sl]; q.dx = L.dx[sl]; q.dy = L.dy[sl]; q.dz = L.dz[sl]; q.flag = L.flag[sl] != 0;
+                force = true;       // the particle arrays are stale: write every field back
+            }
+        }
+    }
     double px = q.x, py = q.y, pz = q.z;          // prior_*_vals (Pore:427-429)
+    const bool wr_acc = need_acc || force;
 
     if (stages & AMC_ST_DRIFT) {                  // Pore:430-437 / Cube:180-187 (ndarray ops: exact products)
         const double sx = dt * q.vx, sy = dt * q.vy, sz = dt * q.vz;
@@ -95,18 +111,18 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         noob = amc_bounds(P, q.x, q.y, q.z, GEOM == AMC_GEOM_PORE_ENERGISED);        // Pore:512 / Temp:804
 
     // write back only what changed (positions and accumulators always change in a drift step)
-    if (q.x != x_in) S.x[p] = q.x;
-    if (q.y != y_in) S.y[p] = q.y;
-    if (q.z != z_in) S.z[p] = q.z;
-    if (q.vx != vx_in) S.vx[p] = q.vx;
-    if (q.vy != vy_in) S.vy[p] = q.vy;
-    if (q.vz != vz_in) S.vz[p] = q.vz;
-    if (need_acc) {
-        if (q.d != d_in) S.d[p] = q.d;
-        if (q.dx != dx_in) S.dx[p] = q.dx;
-        if (q.dy != dy_in) S.dy[p] = q.dy;
-        if (q.dz != dz_in) S.dz[p] = q.dz;
-        if (q.flag != flag_in) S.flag[p] = 1;
+    if (force || q.x != x_in) S.x[p] = q.x;
+    if (force || q.y != y_in) S.y[p] = q.y;
+    if (force || q.z != z_in) S.z[p] = q.z;
+    if (force || q.vx != vx_in) S.vx[p] = q.vx;
+    if (force || q.vy != vy_in) S.vy[p] = q.vy;
+    if (force || q.vz != vz_in) S.vz[p] = q.vz;
+    if (wr_acc) {
+        if (force || q.d != d_in) S.d[p] = q.d;
+        if (force || q.dx != dx_in) S.dx[p] = q.dx;
+        if (force || q.dy != dy_in) S.dy[p] = q.dy;
+        if (force || q.dz != dz_in) S.dz[p] = q.dz;
+        if (force || q.flag != flag_in) S.flag[p] = q.flag ? 1 : 0;
     }
     // fused first pass of the counting sort into the detection grid (amc_grid.hip): the particle's final position of
     // this stage is in registers, so the separate k_bin_count pass over the positions is saved
@@ -128,6 +144,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
 {
     int *cc = nullptr, *cid = nullptr, *rank = nullptr;
     if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { cc = c->B.cell_count; cid = c->B.cid; rank = c->B.rank; }
+    amc_lazy L;
+    memset(&L, 0, sizeof L);
+    if (c->lazy_pending && c->lo == 0 && c->hi == c->n) {
+        const amc_resolve_ws &W = c->W;
+        L.slot_of = W.slot_of; L.x = W.sl_x; L.y = W.sl_y; L.z = W.sl_z; L.vx = W.sl_vx; L.vy = W.sl_vy; L.vz = W.sl_vz;
+        L.d = W.sl_d; L.dx = W.sl_dx; L.dy = W.sl_dy; L.dz = W.sl_dz; L.flag = W.sl_flag; L.moved = W.sl_moved;
+        L.enabled = 1;
+        c->lazy_pending = false;        // this pass consumes them
+    }
     const long long cnt = c->hi - c->lo;
     if (cnt <= 0) return hipSuccess;
     const int threads = 256;
@@ -137,15 +162,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
         break;
     case AMC_GEOM_PORE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
         break;
     case AMC_GEOM_PORE_ENERGISED:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
-                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank);
+                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
         break;
     default:
         break;

@@ -156,10 +156,11 @@ class Engine:
         self._ck(self.lib.amc_profile(self._ctx, int(on)))
 
     def kernel_times(self):
-        ms = np.zeros(8)
-        cnt = np.zeros(8, dtype=np.int64)
+        nk = len(AMC_K_NAMES)
+        ms = np.zeros(nk)
+        cnt = np.zeros(nk, dtype=np.int64)
         self._ck(self.lib.amc_kernel_times(self._ctx, _d(ms), cnt.ctypes.data_as(C.POINTER(C.c_int64))))
-        return {AMC_K_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(8)}
+        return {AMC_K_NAMES[k]: (float(ms[k]), int(cnt[k])) for k in range(nk)}
 
 
 class ShardEngine(Engine):

@@ -27,13 +27,20 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 BYTES_PER_PARTICLE_STEP = 137    # 81 B read + 56 B written by a complete timestep(dt)
 # algorithmic bytes per particle for each kernel class (DESIGN.md "kernels")
-ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 24, "bounds": 24}
+ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 24, "bounds": 24, "resolve": 24}
+KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_count", "bin_scan": "k_scan_block+k_scan_add",
+                   "bin_scatter": "k_bin_scatter", "detect": "k_detect_binned", "resolve": "k_resolve<GEOM,0> (first launch of the sweep)",
+                   "bounds": "k_stream (bounds-only pass)", "validate": "k_validate", "resolve_more": "k_resolve<GEOM,1>",
+                   "commit": "k_commit"}
 
 WORKLOADS = {
     "cube_1e5": ("cube", 100_000),
     "cube_1e6": ("cube", 1_000_000),
     "pore_5e5": ("pore", 500_000),
     "pore_1e6": ("pore", 1_000_000),
+    # BASELINE configs[3]: Temperature_Pore_MC energised walls; every step hands the wall hits to the host, which draws
+    # the re-emission directions from the two Mersenne Twisters in particle order and evaluates mpmath.quad per gap hit
+    "temp_1e6": ("temp", 1_000_000),
 }
 
 
@@ -47,7 +54,7 @@ def make_workload(name, n_override=None, device=0):
         p, c = PR.cube_params_for_n(n, device=device)
         init = IC.cube_ic(p, c, seed=127)
     else:
-        p, c = PR.pore_params(n=n, device=device)
+        p, c = PR.pore_params(n=n, device=device, energised=(kind == "temp"))
         init = IC.pore_ic(p, c, seed=17)
     # count-and-continue on a degenerate wall/contact solve (Temp:340-342 semantics) instead of aborting like Pore:336-338
     p.reserved1 = 1
@@ -117,7 +124,30 @@ def main():
         n_per_gpu = args.n
     stream_ptr = torch.cuda.current_stream().cuda_stream
 
-    if world == 1 and not args.force_sharded:
+    if kind == "temp":
+        import random
+        from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+        from argon_monte_carlo_amd.engine import EnergisedEngine
+        if world != 1:
+            raise SystemExit("the energised-wall workload is single-GPU (host RNG hand-over per step)")
+        p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
+        p.reserved0 |= 1
+        eng = EnergisedEngine(p)
+        eng.set_stream(stream_ptr)
+        eng.upload(*init)
+        sampler = DirectionSampler(np.random.RandomState(17), random.Random(17))
+        energies = SurfaceEnergies(c)
+
+        def step(k):
+            tot = None
+            for _ in range(k):
+                st = eng.temp_timestep(c["dt"], sampler, energies)[0]
+                tot = st if tot is None else {kk: tot[kk] + st[kk] for kk in st}
+            return tot
+        n_total = int(p.n)
+        parallelism = "single GPU + host RNG/mpmath hand-over per energised case"
+        engines = [eng]
+    elif world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
         eng = Engine(p)
         eng.set_stream(stream_ptr)
@@ -172,7 +202,7 @@ def main():
             per_particle = ALGO_BYTES.get(k, 24)
             units = n_local if k in ("drift_walls", "bounds") else n_total
             ach = per_particle * units / avg_s / 1e9
-            roof = {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"kernel": KERNEL_OF_CLASS.get(k, k), "kernel_class": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
                     "algorithmic_bytes_per_launch": per_particle * units,
                     "per_kernel_avg_us": {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]},
@@ -186,7 +216,7 @@ def main():
                        "pp_collisions_per_step": stats["n_pp"] / args.steps if stats else None},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and kind != "temp":
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if world > 1 or args.force_sharded:

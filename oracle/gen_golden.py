@@ -143,7 +143,7 @@ def gen_func():
     def grab():
         return {k: getattr(P, k).copy() for k in STATE_KEYS}
 
-    nw = 600
+    nw = 300
     # vertical walls at several planes
     vplanes = [0.0, float(P.total_height), float(P.total_height - P.open_air_height), float(P.open_air_height),
                float(P.open_air_height + P.hot_coating_height)]
@@ -433,8 +433,8 @@ def main():
     if a.only in ("all", "func"):
         gen_func()
     if a.only in ("all", "cube"):
-        gen_cube("a", K=6000, sigma_mult=4, steps=40, snaps=[0, 1, 5, 20, 39])
-        gen_cube("dense", K=2500, sigma_mult=36, steps=25, snaps=[0, 1, 10, 24])
+        gen_cube("a", K=6000, sigma_mult=4, steps=40, snaps=[0, 20, 39])
+        gen_cube("dense", K=2500, sigma_mult=36, steps=25, snaps=[0, 10, 24])
     if a.only in ("all", "pore"):
         gen_pore("a", K=1500, sigma_mult=100, slice_=1, steps=40, snaps=[0, 1, 5, 20, 39])
     if a.only in ("all", "temp"):
