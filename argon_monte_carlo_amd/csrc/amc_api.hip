@@ -174,6 +174,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.ev_gen, c->W.ev_slot, c->W.hist_gen};
     for (void *p : ptrs)
         if (p) hipFree(p);
+    if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -216,6 +217,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_dbg = nullptr;
     c->mg_count_pp = true;
     c->lazy_pending = false;
+    c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->mg_ncand = 0;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
     c->stream = nullptr;
@@ -309,6 +311,14 @@ int amc_create(amc_ctx **out, const amc_params *p)
             ed[nb] = p->hist_hi;
             CK(hipMemcpy(c->d_edges, ed.data(), sizeof(double) * (nb + 1), hipMemcpyHostToDevice));
             c->out.nbins = nb; c->out.hist = c->d_hist; c->out.edges = c->d_edges;
+        }
+        {
+            void *hp = nullptr, *dp = nullptr;
+            if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+                c->h_host_ncand = (volatile int *)hp;
+                *c->h_host_ncand = 0;
+                c->d_host_ncand = (int *)dp;
+            }
         }
         if (getenv("AMC_DEBUG_RESOLVE")) {
             CK(dalloc(&c->d_dbg, 16));

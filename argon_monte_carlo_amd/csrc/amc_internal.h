@@ -124,6 +124,8 @@ struct amc_ctx {
     void *xchg_send, *xchg_recv;   // xchg_send = state table float64[11][n_list]; xchg_recv = int32 particle list
     int64_t xchg_stride;           // capacity of both, in particles
     bool mg_count_pp;              // this rank adds the p-p collision count to its counters
+    volatile int *h_host_ncand;    // host-mapped word written by k_resolve (candidate count of the last sweep)
+    int *d_host_ncand;             // its device address
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     int mg_ncand;                  // candidate count read back by the last amc_mg_detect
 };

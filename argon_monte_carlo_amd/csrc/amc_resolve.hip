@@ -45,7 +45,9 @@ struct rs_args {
     int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
     int defer_commit;         // leave the results in the slot arrays: the next streaming pass (or k_apply) writes them
     int apply_only;           // k_commit: only write deferred results (amc_flush)
-    int allow_mono;           // small sweeps may run validation + commit inside resolve_A (saves three kernels' latency)
+    int allow_mono;           // small sweeps may run validation + commit inside resolve_A
+    int force_mono;           // the host launched ONLY this kernel (it expects a small sweep): do everything here
+    int *host_ncand;          // host-mapped word: candidate count of this sweep, read (lagging) by the host to pick the launch plan (saves three kernels' latency)
     int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
     double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
@@ -531,6 +533,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             sh.nfp = 0; sh.ovf = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
             sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0; sh.nslots0 = 0;
             cnt->cand_count = 0;
+            if (A.host_ncand) *A.host_ncand = ncand;
             if (ncand == 0) *ctl = sh;
         }
         __syncthreads();
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     // MODE 2 always, MODE 0 for small sweeps: validation and commit in this kernel (the wide kernels then find
     // ctl.active == 0 and exit); large sweeps hand over after the first round
-    const bool mono = (MODE == 2) || (MODE == 0 && A.allow_mono && ncand <= RS_SMALL);
+    const bool mono = (MODE == 2) || (MODE == 0 && A.allow_mono && (A.force_mono || ncand <= RS_SMALL));
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
     V.p = W.sl_p;
@@ -916,6 +919,15 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
         hipLaunchKernelGGL((k_resolve<GEOM, 2>), dim3(1), dim3(RS_T), 0, c->stream, A);
         return;
     }
+    // launch plan from the candidate count of the most recent sweep the host has seen (a word the kernel writes into
+    // host-mapped memory; no synchronisation, it may lag by a step): small sweeps need only this one kernel.  Either
+    // plan is correct for any count — a wrong guess only costs time.
+    if (c->h_host_ncand && *c->h_host_ncand <= RS_SMALL) {
+        rs_args B = A;
+        B.force_mono = 1;
+        hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, B);
+        return;
+    }
     hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_VALIDATE);
@@ -935,6 +947,8 @@ static rs_args rs_make_args(amc_ctx *c)
     A.dbg = c->d_dbg;
     A.single_round = 0;
     A.allow_mono = 1;
+    A.force_mono = 0;
+    A.host_ncand = c->d_host_ncand;
     A.defer_commit = 0;
     A.apply_only = 0;
     A.count_pp = c->mg_count_pp ? 1 : 0;
