@@ -161,8 +161,7 @@ void amc_destroy(amc_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
-                    c->S.pz, c->S.flag, c->d_lay, c->B.sp, c->B.cell_start, c->B.cell_count,
-                    c->B.cid, c->B.rank, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
+                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
                     c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
                     c->W.edge_b, c->W.hist_slot, c->W.hist_x, c->W.hist_y, c->W.hist_z, c->W.ov_head, c->W.ov_next,
@@ -249,12 +248,11 @@ int amc_create(amc_ctx **out, const amc_params *p)
         if ((rc = setup_grid(c)) != AMC_OK) goto fail;
         if (!c->allpairs) {
             const size_t nc = (size_t)c->G.ncells;
-            CK(dalloc(&c->B.sp, n));
-            CK(dalloc(&c->B.cid, n)); CK(dalloc(&c->B.rank, n));
-            CK(dalloc(&c->B.cell_start, nc + 1)); CK(dalloc(&c->B.cell_count, nc + 1));
-            CK(hipMemsetAsync(c->B.cell_count, 0, sizeof(int) * (nc + 1), c->stream));
-            c->scan_blocks = (int)((nc + 4095) / 4096);
-            CK(dalloc(&c->scan_tmp, (size_t)c->scan_blocks + 1));
+            CK(dalloc(&c->B.rec, n));
+            CK(dalloc(&c->B.head, nc + 1));
+            CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
+            c->B.epoch = 0;
+            c->scan_blocks = 0;
             CK(dalloc(&c->W.ov_head, nc));
             CK(hipMemsetAsync(c->W.ov_head, 0xff, sizeof(int) * std::max<size_t>(nc, 1), c->stream));
         }
@@ -466,7 +464,7 @@ static int amc_flush(amc_ctx *c)
 
 static int enqueue_sweep(amc_ctx *c, bool counted = false, bool defer_commit = false)
 {
-    AMC_HIP(c, amc_launch_bin(c, counted));
+    if (!counted) AMC_HIP(c, amc_launch_bin(c));
     AMC_HIP(c, amc_launch_detect(c));
     AMC_HIP(c, amc_launch_resolve(c, defer_commit));
     if (defer_commit) c->lazy_pending = true;
@@ -483,7 +481,6 @@ static int enqueue_step(amc_ctx *c, double dt)
     } else if (g == AMC_GEOM_CUBE || g == AMC_GEOM_PORE) {
         // the streaming pass also counts the particles into the detection grid when it covers all of them
         const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
-        if (fuse) AMC_HIP(c, amc_launch_bin_clear(c));
         const int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
         AMC_HIP(c, amc_launch_stream(c, dt, st, 0, fuse));
         // the scattered commit is deferred: the next streaming pass over all particles (the bounds check for the pore,

@@ -1,4 +1,4 @@
-// amc_grid_dev.h — device helpers of the detection grid (uniform cells, per-z-layer square window).
+// amc_grid_dev.h — device helpers of the detection grid (uniform cells, per-z-layer square window, per-cell lists).
 #pragma once
 #include "amc_internal.h"
 
@@ -24,25 +24,6 @@ AMC_DEV int amc_grid_cell(const amc_grid &G, int cx, int cy, int cz, bool *outsi
         ly = amc_clampi(ly, 0, n - 1);
     }
     return G.lay_off[cz] + ly * n + lx;
-}
-
-// cells (cx-1..cx+1, cy, cz) clipped to the layer's window: contiguous ids [c_lo, c_hi]; false if the row is empty
-AMC_DEV bool amc_grid_row(const amc_grid &G, int cx, int cy, int cz, int &c_lo, int &c_hi)
-{
-    if (cz < 0 || cz >= G.gz) return false;
-    const int lo = G.lay_lo[cz], n = G.lay_n[cz];
-    const int ly = cy - lo;
-    if (ly < 0 || ly >= n) return false;
-    // a stored particle may have been clamped into the window edge; querying from the true coordinates keeps
-    // in-window pairs exact
-    int x_lo = cx - 1 - lo, x_hi = cx + 1 - lo;
-    if (x_lo < 0) x_lo = 0;
-    if (x_hi > n - 1) x_hi = n - 1;
-    if (x_lo > x_hi) return false;
-    const int base = G.lay_off[cz] + ly * n;
-    c_lo = base + x_lo;
-    c_hi = base + x_hi;
-    return true;
 }
 
 // The stored cells that can hold a particle within distance r (<= h/2) of (x,y,z), as up to four runs of x-adjacent
@@ -77,6 +58,23 @@ AMC_DEV int amc_grid_box_ranges(const amc_grid &G, double x, double y, double z,
     return n;
 }
 
-// particle index stored in the 4th lane of a sorted record
-AMC_DEV int amc_sp_index(const double4 &r) { return (int)__double_as_longlong(r.w); }
-AMC_DEV double amc_sp_pack(int idx) { return __longlong_as_double((long long)idx); }
+// ---- per-cell lists -----------------------------------------------------------------------------------------------------
+AMC_DEV int amc_rec_next(const double4 &r) { return (int)__double_as_longlong(r.w); }
+AMC_DEV double amc_rec_pack(int next) { return __longlong_as_double((long long)next); }
+// first particle of cell c in the current epoch, or -1
+AMC_DEV int amc_list_head(const amc_sorted &B, int c)
+{
+    const unsigned long long h = B.head[c];
+    return ((unsigned int)(h >> 32) == B.epoch) ? (int)(unsigned int)(h & 0xffffffffULL) : -1;
+}
+// push particle p (position x,y,z) on the list of its cell; writes its record
+AMC_DEV void amc_list_insert(const amc_grid &G, const amc_sorted &B, int p, double x, double y, double z, bool *outside)
+{
+    int cx, cy, cz;
+    amc_grid_coords(G, x, y, z, cx, cy, cz);
+    const int c = amc_grid_cell(G, cx, cy, cz, outside);
+    const unsigned long long mine = ((unsigned long long)B.epoch << 32) | (unsigned int)p;
+    const unsigned long long old = atomicExch(&B.head[c], mine);
+    const int next = ((unsigned int)(old >> 32) == B.epoch) ? (int)(unsigned int)(old & 0xffffffffULL) : -1;
+    B.rec[p] = make_double4(x, y, z, amc_rec_pack(next));
+}

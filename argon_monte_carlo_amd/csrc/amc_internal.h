@@ -29,11 +29,14 @@ struct amc_grid {
     const int *lay_off;       // [gz] linear offset of the layer's first cell
 };
 
+// Per-cell particle lists of the detection grid, rebuilt every step with ONE 64-bit atomic exchange per particle:
+//   head[c] = (epoch << 32) | particle   — a head whose epoch is not the current one means "empty", so nothing is ever
+//                                          re-zeroed and no scan / scatter pass is needed;
+//   rec[p]  = (x, y, z, next-particle-as-bits) — 32 bytes, written coalesced (indexed by the particle itself).
 struct amc_sorted {
-    double4 *sp;              // cell-ordered copy, ONE 32-byte record per particle: x, y, z, particle index (as bits)
-    int *cell_start;          // [ncells+1] exclusive prefix of the per-cell counts
-    int *cell_count;          // [ncells]
-    int *cid, *rank;          // [n] cell id and arrival rank of each particle
+    unsigned long long *head; // [ncells]
+    double4 *rec;             // [n]
+    unsigned int epoch;       // current binning epoch (>= 1)
 };
 
 // results of the last sweep that have not been written to the particle arrays yet: the next streaming pass picks them
@@ -100,7 +103,7 @@ struct amc_ctx {
     std::vector<int> h_lay_lo, h_lay_n, h_lay_off;
     int *d_lay;               // device copy of the three layer tables, contiguous
     amc_sorted B;
-    int *scan_tmp;
+    int *scan_tmp;            // (unused since the counting sort was replaced by per-cell lists)
     int scan_blocks;
     amc_resolve_ws W;
     amc_temp_ws T;
@@ -150,8 +153,7 @@ void amc_prof_collect(amc_ctx *c);
 
 // launchers (each enqueues on c->stream; returns hipError_t of the launch)
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin = false);
-hipError_t amc_launch_bin_clear(amc_ctx *c);           // zero the per-cell counters (before a fused-count stream pass)
-hipError_t amc_launch_bin(amc_ctx *c, bool counted = false);   // [count +] scan + scatter over all n particles
+hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build over all n particles (stages, multi-GPU)
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_apply(amc_ctx *c);                // write deferred sweep results to the particle arrays now

@@ -413,7 +413,6 @@ AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
     sh->dirty = 1;
 }
 
-#define RS_VAL_BATCH 8         // neighbour entries fetched per validation batch
 
 // validation probe of history entry h: its position against every particle outside its cluster.  `cnt` are the
 // sweep counters (LDS inside a resolve kernel, W.ctl in the wide validate kernel), `label` the per-slot labels.
@@ -427,31 +426,25 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
     // only the cells overlapped by the collision_range box around the new position can hold a partner (1.7 cells on
     // average): fetch their bounds and overlay heads first, then the entries in batches
-    int c_lo[4], c_hi[4], q0[4], q1[4], ovh[8];
+    int c_lo[4], c_hi[4], lh[8], ovh[8];
     const int ncell = amc_grid_box_ranges(G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
+    // list heads and overlay heads of every overlapped cell first (one memory round trip), then the entries
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        q0[k] = q1[k] = 0; ovh[2 * k] = ovh[2 * k + 1] = -1;
+        lh[2 * k] = lh[2 * k + 1] = -1; ovh[2 * k] = ovh[2 * k + 1] = -1;
         if (k < ncell) {
-            q0[k] = A.B.cell_start[c_lo[k]]; q1[k] = A.B.cell_start[c_hi[k] + 1];
-            ovh[2 * k] = W.ov_head[c_lo[k]];
-            if (c_hi[k] != c_lo[k]) ovh[2 * k + 1] = W.ov_head[c_hi[k]];
+            lh[2 * k] = amc_list_head(A.B, c_lo[k]); ovh[2 * k] = W.ov_head[c_lo[k]];
+            if (c_hi[k] != c_lo[k]) { lh[2 * k + 1] = amc_list_head(A.B, c_hi[k]); ovh[2 * k + 1] = W.ov_head[c_hi[k]]; }
         }
     }
-    int bq[RS_VAL_BATCH];
-    int nb = 0;
-    auto flush = [&]() {
-        double ex[RS_VAL_BATCH], ey[RS_VAL_BATCH], ez[RS_VAL_BATCH];
-        int bi[RS_VAL_BATCH];
-#pragma unroll
-        for (int k = 0; k < RS_VAL_BATCH; k++)
-            if (k < nb) { const double4 r = A.B.sp[bq[k]]; ex[k] = r.x; ey[k] = r.y; ez[k] = r.z; bi[k] = amc_sp_index(r); }
-#pragma unroll
-        for (int k = 0; k < RS_VAL_BATCH; k++) {
-            if (k >= nb) continue;
-            const int idx = bi[k];
+    // pre-sweep positions of the particles binned into those cells
+    for (int k = 0; k < 2 * ncell; k++)
+        for (int q = lh[k]; q >= 0;) {
+            const double4 r = A.B.rec[q];
+            const int idx = q;
+            q = amc_rec_next(r);
             if (idx == pme) continue;
-            const double ax = ex[k] - x, ay = ey[k] - y, az = ez[k] - z;
+            const double ax = r.x - x, ay = r.y - y, az = r.z - z;
             if (ax * ax + ay * ay + az * az < cr2i) {
                 const int so = W.slot_of[idx];
                 if (so >= 0 && so < ns && label[so] == lme) continue;
@@ -459,14 +452,6 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
                 rs_add_edge(W, cnt, pme, idx);
             }
         }
-        nb = 0;
-    };
-    for (int k = 0; k < ncell; k++)
-        for (int q = q0[k]; q < q1[k]; q++) {
-            bq[nb++] = q;
-            if (nb == RS_VAL_BATCH) flush();
-        }
-    if (nb) flush();
     // new positions of other clusters' members (overlay lists of the same cells)
     for (int k = 0; k < 2 * ncell; k++)
         for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {

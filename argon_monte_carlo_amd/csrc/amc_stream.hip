@@ -15,7 +15,7 @@
 template <int GEOM>
 __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
                                                 long long lo, long long hi, int keep_prior, int bounds_slot,
-                                                amc_grid G, int *cell_count, int *cid, int *rank, amc_lazy L)
+                                                amc_grid G, amc_sorted B, int build_lists, amc_lazy L)
 {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
@@ -124,16 +124,12 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         if (force || q.dz != dz_in) S.dz[p] = q.dz;
         if (force || q.flag != flag_in) S.flag[p] = q.flag ? 1 : 0;
     }
-    // fused first pass of the counting sort into the detection grid (amc_grid.hip): the particle's final position of
-    // this stage is in registers, so the separate k_bin_count pass over the positions is saved
-    if (cell_count) {
-        int cx, cy, cz;
-        amc_grid_coords(G, q.x, q.y, q.z, cx, cy, cz);
+    // fused build of the detection grid's per-cell lists (amc_grid.hip): the particle's final position of this stage
+    // is in registers, so no separate binning pass over the positions is needed
+    if (build_lists) {
         bool outside = false;
-        const int c = amc_grid_cell(G, cx, cy, cz, &outside);
+        amc_list_insert(G, B, (int)p, q.x, q.y, q.z, &outside);
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
-        cid[p] = c;
-        rank[p] = atomicAdd(&cell_count[c], 1);
     }
     if (nwall) atomicAdd(&O.cnt->n_wall, (unsigned long long)nwall);
     if (nerr) atomicAdd(&O.cnt->n_fp_errors, (unsigned long long)nerr);
@@ -142,8 +138,8 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
 
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin)
 {
-    int *cc = nullptr, *cid = nullptr, *rank = nullptr;
-    if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { cc = c->B.cell_count; cid = c->B.cid; rank = c->B.rank; }
+    int build = 0;
+    if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { build = 1; c->B.epoch++; }
     amc_lazy L;
     memset(&L, 0, sizeof L);
     if (c->lazy_pending && c->lo == 0 && c->hi == c->n) {
@@ -162,15 +158,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
         break;
     case AMC_GEOM_PORE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
         break;
     case AMC_GEOM_PORE_ENERGISED:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
-                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, cc, cid, rank, L);
+                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
         break;
     default:
         break;

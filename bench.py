@@ -28,8 +28,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md);
 BYTES_PER_PARTICLE_STEP = 137    # 81 B read + 56 B written by a complete timestep(dt)
 # algorithmic bytes per particle for each kernel class (DESIGN.md "kernels")
 ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 24, "bounds": 24, "resolve": 24}
-KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_count", "bin_scan": "k_scan_block+k_scan_add",
-                   "bin_scatter": "k_bin_scatter", "detect": "k_detect_binned", "resolve": "k_resolve<GEOM,0> (first launch of the sweep)",
+KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_lists",
+                   "detect": "k_detect_lists", "resolve": "k_resolve<GEOM,0> (first launch of the sweep)",
                    "bounds": "k_stream (bounds-only pass)", "validate": "k_validate", "resolve_more": "k_resolve<GEOM,1>",
                    "commit": "k_commit"}
 

@@ -258,9 +258,9 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 /* ---- measurement ----------------------------------------------------------------------------------------- */
 /* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
 #define AMC_K_DRIFT_WALLS 0
-#define AMC_K_BIN_COUNT 1
-#define AMC_K_BIN_SCAN 2
-#define AMC_K_BIN_SCATTER 3
+#define AMC_K_BIN_COUNT 1        /* k_bin_lists: stand-alone build of the per-cell lists (the step driver fuses it into k_stream) */
+#define AMC_K_BIN_SCAN 2         /* unused */
+#define AMC_K_BIN_SCATTER 3      /* unused */
 #define AMC_K_DETECT 4
 #define AMC_K_RESOLVE 5          /* k_resolve, first launch of a sweep (claim, clusters, emulation; small sweeps: everything) */
 #define AMC_K_BOUNDS 6
