@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_sorted B, 
         for (int k = 0; k < nc; k++)
             for (int c = c_lo[k]; c <= c_hi[k]; c++)
                 for (int q = amc_list_head(B, c); q >= 0;) {
+                    if (q == (int)p) { q = amc_rec_next(me); continue; }     // my own record is already in registers
                     const double4 o = B.rec[q];
                     const int qn = amc_rec_next(o);
                     if (q < (int)p) {

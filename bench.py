@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
+    ap.add_argument("--sorted-ic", action="store_true", help="experiment: upload the particles in spatial (cell) order")
     ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
     args = ap.parse_args()
 
