@@ -87,28 +87,42 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_sorted B, 
     int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
     if (p < n) {
         const double4 me = B.rec[p];
+        auto found_pair = [&](int q) {
+            const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt);
+            if (my_k >= 0 && kk >= 0) {
+                const int hi = (int)p > q ? (int)p : q, lo = (int)p > q ? q : (int)p;
+                for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
+                    cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? hi : lo, e % 11);
+            } else if (kk >= 0) {
+                my_k = kk; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
+            }
+        };
+        // my own cell: only the particles inserted BEFORE me (my `next` chain) — every same-cell pair is thereby met
+        // exactly once, by the later-inserted particle, and the cell's head need not be loaded at all
+        for (int q = amc_rec_next(me); q >= 0;) {
+            const double4 o = B.rec[q];
+            const double ex = o.x - me.x, ey = o.y - me.y, ez = o.z - me.z;
+            if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q);
+            q = amc_rec_next(o);
+        }
+        // the other cells my box overlaps (0.7 on average): a cross-cell pair is met from both ends, the larger index emits
+        int ocx, ocy, ocz;
+        amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
+        const int c_own = amc_grid_cell(G, ocx, ocy, ocz, nullptr);
         int c_lo[4], c_hi[4];
         const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
         for (int k = 0; k < nc; k++)
-            for (int c = c_lo[k]; c <= c_hi[k]; c++)
+            for (int c = c_lo[k]; c <= c_hi[k]; c++) {
+                if (c == c_own) continue;
                 for (int q = amc_list_head(B, c); q >= 0;) {
-                    if (q == (int)p) { q = amc_rec_next(me); continue; }     // my own record is already in registers
                     const double4 o = B.rec[q];
-                    const int qn = amc_rec_next(o);
                     if (q < (int)p) {
                         const double ex = o.x - me.x, ey = o.y - me.y, ez = o.z - me.z;
-                        if (ex * ex + ey * ey + ez * ez < cr2i) {
-                            const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt);
-                            if (my_k >= 0 && kk >= 0) {
-                                for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
-                                    cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? (int)p : q, e % 11);
-                            } else {
-                                my_k = kk; my_i = (int)p; my_j = q;
-                            }
-                        }
+                        if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q);
                     }
-                    q = qn;
+                    q = amc_rec_next(o);
                 }
+            }
     }
     const unsigned long long found = __ballot(my_k >= 0);
     if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);
