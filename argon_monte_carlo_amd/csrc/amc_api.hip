@@ -308,7 +308,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
             for (int k = 0; k <= nb; k++) ed[k] = p->hist_lo + (double)k * step;
             ed[nb] = p->hist_hi;
             CK(hipMemcpy(c->d_edges, ed.data(), sizeof(double) * (nb + 1), hipMemcpyHostToDevice));
-            c->out.nbins = nb; c->out.hist = c->d_hist; c->out.edges = c->d_edges;
+            c->out.nbins = nb; c->out.hist = c->d_hist; c->out.edges = c->d_edges; c->out.bin_step = step;
         }
         {
             void *hp = nullptr, *dp = nullptr;

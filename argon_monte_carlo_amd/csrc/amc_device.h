@@ -30,7 +30,8 @@ struct amc_out {
     amc_path_record *rec;
     unsigned int cap;
     unsigned long long *hist;           // [4][nbins]
-    const double *edges;                // [nbins+1] = np.linspace(lo, hi, nbins+1), uploaded by the host
+    const double *edges;                // [nbins+1] = np.linspace(lo, hi, nbins+1) (kept for reference; recomputed on the fly)
+    double bin_step;                    // (hi - lo) / nbins: edge k = lo + k * bin_step, edge nbins = hi — np.linspace's formula
     int nbins;
     double lo, hi;
     amc_dev_counters *cnt;
@@ -45,8 +46,11 @@ AMC_DEV int amc_hist_bin(const amc_out &o, double v)
     double f = ((v - o.lo) / (o.hi - o.lo)) * (double)o.nbins;
     int idx = (int)f;
     if (idx == o.nbins) idx -= 1;
-    if (v < o.edges[idx]) idx -= 1;
-    else if (v >= o.edges[idx + 1] && idx != o.nbins - 1) idx += 1;
+    // bin edges recomputed instead of loaded (saves two dependent memory round trips per value)
+    const double e0 = o.lo + (double)idx * o.bin_step;
+    const double e1 = (idx + 1 == o.nbins) ? o.hi : o.lo + (double)(idx + 1) * o.bin_step;
+    if (v < e0) idx -= 1;
+    else if (v >= e1 && idx != o.nbins - 1) idx += 1;
     return idx;
 }
 

@@ -818,9 +818,10 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     const int ns = ctl->nslots < W.max_slots ? ctl->nslots : W.max_slots;
     const int nev = ctl->nev < W.max_events ? ctl->nev : W.max_events;
     const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
+    int my_hits = 0;
     for (int s = gtid; s < ns; s += gstride) {
         const int p = W.sl_p[s];
-        if (ok && A.count_pp && W.sl_hits[s]) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)W.sl_hits[s]);
+        if (ok && A.count_pp) my_hits += W.sl_hits[s];
         if (defer) continue;
         if (ok && W.sl_moved[s]) {
             A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
@@ -830,6 +831,9 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         }
         W.slot_of[p] = -1;
     }
+    // one atomic per wave instead of one per slot on a single counter word
+    for (int o = 32; o > 0; o >>= 1) my_hits += __shfl_down(my_hits, o, 64);
+    if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)my_hits);
     if (ok)
         for (int e = gtid; e < nev; e += gstride) {
             if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;          // event of an emulation that was redone since
