@@ -169,7 +169,7 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
 // ---- launchers ---------------------------------------------------------------------------------------------------
 hipError_t amc_launch_bin(amc_ctx *c)
 {
-    if (c->allpairs) return hipSuccess;
+    if (c->allpairs || c->n <= 0) return hipSuccess;
     const long long n = c->n;
     c->B.epoch++;
     amc_prof_begin(c, AMC_K_BIN_COUNT);
@@ -182,6 +182,7 @@ hipError_t amc_launch_bin(amc_ctx *c)
 hipError_t amc_launch_detect(amc_ctx *c)
 {
     const long long n = c->n;
+    if (n <= 0) return hipSuccess;
     const double cr2i = c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {

@@ -431,3 +431,76 @@ def test_temp_1e6_two_steps_vs_oracle(O):
         assert (m, ec, eh) == (m2, ec2, eh2) and st["n_wall"] > 100
         assert_state_equal(eng.download(), orc.state(), ("temp1e6", s))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17])
+@pytest.mark.parametrize("kind", ["cube", "pore"])
+def test_tiny_and_empty_systems(Engine, O, kind, n):
+    """Empty / tiny inputs through the full step (both detectors): same result as the oracle, no launch errors."""
+    rng = np.random.default_rng(n + 5)
+    for mode in (1, 2):
+        p, c = (PR.cube_params(n=n) if kind == "cube" else PR.pore_params(n=n))
+        p.detect_mode = mode
+        eng = Engine(p)
+        orc = O.Oracle(p, mode="mul")
+        if kind == "cube":
+            pos = rng.random((3, n)) * 2e-9 + 49e-9            # packed tightly so that the few particles interact
+        else:
+            pos = np.stack([rng.random(n) * 2e-9, rng.random(n) * 2e-9, 1.5e-6 + rng.random(n) * 2e-9])
+        vel = rng.normal(size=(3, n)) * 300.0
+        eng.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        orc.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        for s in range(4):
+            st = eng.timestep(c["dt"])
+            rc, so = orc.timestep(c["dt"])
+            assert rc == 0 and st["n_pp"] == so["n_pp"] and st["n_wall"] == so["n_wall"], (kind, n, mode, s, st, so)
+            assert_state_equal(eng.download(), orc.state(), (kind, n, mode, s))
+        assert eng.run(c["dt"], 0) is not None
+        eng.close()
+
+
+def test_dense_cluster_chains_match_oracle(Engine, O):
+    """A dense blob (volume fraction ~20 %): long collision chains and many validation rounds; both detectors agree
+    with the oracle bit for bit."""
+    n = 400
+    rng = np.random.default_rng(99)
+    for mode in (1, 2):
+        p, c = PR.cube_params(n=n)
+        p.detect_mode = mode
+        cr = p.collision_range
+        side = (n * (4.0 / 3.0) * np.pi * (cr / 2) ** 3 / 0.2) ** (1.0 / 3.0)
+        pos = rng.random((3, n)) * side + 40e-9
+        vel = rng.normal(size=(3, n)) * 250.0
+        eng = Engine(p)
+        orc = O.Oracle(p, mode="mul")
+        eng.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        orc.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        dt = 2.0e-14
+        tot = 0
+        for s in range(6):
+            st = eng.timestep(dt)
+            rc, so = orc.timestep(dt)
+            assert rc == 0 and st["n_pp"] == so["n_pp"], (mode, s, st, so)
+            tot += st["n_pp"]
+            assert_state_equal(eng.download(), orc.state(), ("dense", mode, s))
+        assert tot > 100
+        eng.close()
+
+
+def test_candidate_overflow_is_reported_not_silent(Engine):
+    from argon_monte_carlo_amd._lib import ArgonMCError
+    n = 3000
+    rng = np.random.default_rng(1)
+    p, c = PR.cube_params(n=n)
+    p.detect_mode = 2
+    p.max_candidates = 16
+    cr = p.collision_range
+    pos = rng.random((3, n)) * 6 * cr + 40e-9                   # everything overlaps everything
+    vel = rng.normal(size=(3, n)) * 250.0
+    eng = Engine(p)
+    eng.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+    with pytest.raises(ArgonMCError) as ei:
+        eng.timestep(1e-14)
+    assert ei.value.code == -4
+    eng.close()
