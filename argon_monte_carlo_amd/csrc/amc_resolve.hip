@@ -517,6 +517,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             sh.nslots = 0; sh.nedges = 0; sh.nhist = 0; sh.nev = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
             sh.nfp = 0; sh.ovf = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
             sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0; sh.nslots0 = 0;
+            sh.lazy_ns = 0;         // the streaming pass before this sweep consumed the previous sweep's deferred results
             cnt->cand_count = 0;
             if (A.host_ncand) *A.host_ncand = ncand;
             if (ncand == 0) *ctl = sh;
@@ -615,20 +616,66 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 if (k < RS_SORT_LDS) keys[k] = key; else W.sl_key[k] = key;
             }
         }
+        __syncthreads();
         RS_STAMP(6);
-        // ---- two-particle clusters straight from the candidate list, both particles in registers ----------------------------
-        for (int k = tid; k < ncand; k += RS_T) {
-            const int si = W.cand_si[k], sj = W.cand_sj[k];
-            if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
-            if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
-            rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
+        const int nc = sh.ncomplex;
+        // Usually there are only a few such members: then ONE wave runs their whole pipeline (rank sort, load, literal
+        // emulation, write-back) with wave-level synchronisation while the other seven waves do the two-particle
+        // clusters — the two kinds of cluster are disjoint, so the phases overlap instead of following each other.
+        const bool split = nc > 0 && nc <= 64 && nc <= RS_POOL;
+        rs_work K;
+        K.x = pool_d[0]; K.y = pool_d[1]; K.z = pool_d[2]; K.vx = pool_d[3]; K.vy = pool_d[4]; K.vz = pool_d[5];
+        K.d = pool_d[6]; K.dx = pool_d[7]; K.dy = pool_d[8]; K.dz = pool_d[9];
+        K.tmp = pool_tmp; K.pidx = pool_pidx; K.flag = pool_flag; K.moved = pool_moved;
+        if (split && tid < 64) {
+            unsigned long long *sorted = lds_keys + RS_SORT_LDS / 2;
+            const int w = tid;
+            unsigned long long mykey = 0;
+            int rank = 0;
+            if (w < nc) {
+                mykey = keys[w];
+                for (int k = 0; k < nc; k++) rank += keys[k] < mykey;          // keys are unique: rank sort
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (w < nc) sorted[rank] = mykey;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (w < nc) {
+                const int p = (int)(sorted[w] & 0xffffffffULL);
+                const amc_particle q = rs_load_particle(A.S, p);
+                rs_store_work(K, w, q);
+                K.moved[w] = 0;
+                K.pidx[w] = p;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (w < nc) {
+                const unsigned lab = (unsigned)(sorted[w] >> 32);
+                if (!(w > 0 && (unsigned)(sorted[w - 1] >> 32) == lab)) {        // cluster head
+                    int e = w + 1;
+                    while (e < nc && (unsigned)(sorted[e] >> 32) == lab) e++;
+                    if (e - w >= 2) rs_emulate_generic(A, &sh, K, w, e);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (w < nc && K.moved[w]) rs_store_slot(W, W.slot_of[K.pidx[w]], rs_load_work(K, w));
+        } else {
+            // ---- two-particle clusters straight from the candidate list, both particles in registers ------------------------
+            const int t0 = split ? tid - 64 : tid, tstride = split ? RS_T - 64 : RS_T;
+            for (int k = t0; k < ncand; k += tstride) {
+                const int si = W.cand_si[k], sj = W.cand_sj[k];
+                if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
+                if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
+                rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
+            }
         }
         RS_STAMP(7);
         __syncthreads();
         RS_STAMP(2);
         // ---- larger clusters: sort members by (label, index), working set in LDS when it fits ----------------------------
-        const int nc = sh.ncomplex;
-        if (nc > 0) {
+        if (nc > 0 && !split) {
             int m = 1;
             while (m < nc) m <<= 1;
             if (nc > RS_SORT_LDS) {
@@ -638,12 +685,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             for (int k = nc + tid; k < m; k += RS_T) keys[k] = ~0ULL;
             __syncthreads();
             rs_bitonic(keys, m);
-            rs_work K;
-            if (nc <= RS_POOL) {
-                K.x = pool_d[0]; K.y = pool_d[1]; K.z = pool_d[2]; K.vx = pool_d[3]; K.vy = pool_d[4]; K.vz = pool_d[5];
-                K.d = pool_d[6]; K.dx = pool_d[7]; K.dy = pool_d[8]; K.dz = pool_d[9];
-                K.tmp = pool_tmp; K.pidx = pool_pidx; K.flag = pool_flag; K.moved = pool_moved;
-            } else {
+            if (nc > RS_POOL) {
                 K.x = W.cw_d[0]; K.y = W.cw_d[1]; K.z = W.cw_d[2]; K.vx = W.cw_d[3]; K.vy = W.cw_d[4]; K.vz = W.cw_d[5];
                 K.d = W.cw_d[6]; K.dx = W.cw_d[7]; K.dy = W.cw_d[8]; K.dz = W.cw_d[9];
                 K.tmp = W.cw_tmp; K.pidx = W.cw_pidx; K.flag = W.cw_flag; K.moved = W.cw_moved;
