@@ -5,10 +5,10 @@
 // superset of the pairs the reference can hit; the ordered resolve (amc_resolve.hip) then re-tests each pair with
 // the reference's own cell membership and loop order.  Two detectors:
 //
-//   binned   : per-cell particle lists over cells of edge h ~ mean spacing (>= 2 collision_range), built with one
-//              epoch-tagged 64-bit atomic exchange per particle (inside k_stream) - no counters to clear, no scan,
-//              no scatter; then each particle walks the lists of the cells its collision_range box overlaps (1.7 on
-//              average).  O(N) work, HBM/L2-bound.  Algorithmic traffic 24 B/particle (positions read once); the
+//   binned   : per-cell particle lists over cells of edge h ~ 0.63 x mean spacing (>= 2 collision_range), built with
+//              one epoch-tagged 64-bit atomic exchange per particle (inside k_stream) - no counters to clear, no
+//              scan, no scatter; then each particle walks its own list and those of the lower-numbered cells its
+//              collision_range box overlaps.  O(N) work, HBM/L2-bound.  Algorithmic traffic 24 B/particle (positions read once); the
 //              32-byte records and the list heads are implementation overhead.
 //   all-pairs: LDS-tiled j-block (256 particles = 6 KB) against 256 i-particles in registers, upper triangle of
 //              tiles only — the kernel the reference's pairwise_particles_in_cell maps to directly; fp64-VALU-bound
@@ -77,8 +77,11 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 }
 
 // ---- binned detection: one thread per particle ----------------------------------------------------------------------------
-// Each particle walks the lists of the cells overlapped by its +-collision_range box (1.7 cells on average) and tests
-// the particles found there; a pair is seen from both ends and emitted by the end with the larger index.
+// Each particle walks its own cell's list (the part inserted before it) and the lists of the lower-numbered cells its
+// +-collision_range box overlaps; every close pair is met exactly once and stored as (larger index, smaller index).
+// Measured on MI355X (tools/ubench_vmem.hip): random 8..32-byte loads over a >L2 footprint run at ~5.5e10 requests/s
+// whatever their width, index-ordered ones at ~2e11/s — the kernel's cost is its number of random requests
+// (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
 __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_sorted B, long long n, double cr2i, double cr_probe,
                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
                                                       amc_state S, double *cst)
@@ -97,32 +100,51 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_sorted B, 
                 my_k = kk; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
             }
         };
-        // my own cell: only the particles inserted BEFORE me (my `next` chain) — every same-cell pair is thereby met
-        // exactly once, by the later-inserted particle, and the cell's head need not be loaded at all
-        for (int q = amc_rec_next(me); q >= 0;) {
-            const double4 o = B.rec[q];
-            const double ex = o.x - me.x, ey = o.y - me.y, ez = o.z - me.z;
-            if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q);
-            q = amc_rec_next(o);
-        }
-        // the other cells my box overlaps (0.7 on average): a cross-cell pair is met from both ends, the larger index emits
-        int ocx, ocy, ocz;
-        amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
-        const int c_own = amc_grid_cell(G, ocx, ocy, ocz, nullptr);
-        int c_lo[4], c_hi[4];
-        const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
-        for (int k = 0; k < nc; k++)
-            for (int c = c_lo[k]; c <= c_hi[k]; c++) {
-                if (c == c_own) continue;
-                for (int q = amc_list_head(B, c); q >= 0;) {
-                    const double4 o = B.rec[q];
-                    if (q < (int)p) {
-                        const double ex = o.x - me.x, ey = o.y - me.y, ez = o.z - me.z;
-                        if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q);
-                    }
-                    q = amc_rec_next(o);
+        // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
+        // every same-cell pair is thereby met exactly once, by the later-inserted particle, and the head is not needed);
+        // slots 1..8: the other cells my box overlaps, but only those with a SMALLER cell id: two particles closer than
+        // collision_range lie in each other's box, so a cross-cell pair is met exactly once, from the larger cell.  The kernel is bound by the LATENCY of dependent loads (head -> record -> next record),
+        // so all cursors advance together: every round issues the loads of all live cursors before using any of them.
+        int q[9];
+        q[0] = amc_rec_next(me);
+        {
+            int ocx, ocy, ocz;
+            amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
+            const int c_own = amc_grid_cell(G, ocx, ocy, ocz, nullptr);
+            int c_lo[4], c_hi[4];
+            const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
+            int cell[8];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int c = c_lo[k < nc ? k : 0] + t;
+                    cell[2 * k + t] = (k < nc && c <= c_hi[k < nc ? k : 0] && c < c_own) ? c : -1;
                 }
-            }
+            unsigned long long hv[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) hv[e] = (cell[e] >= 0) ? B.head[cell[e]] : 0ULL;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                q[1 + e] = (cell[e] >= 0 && (unsigned int)(hv[e] >> 32) == B.epoch) ? (int)(unsigned int)(hv[e] & 0xffffffffULL) : -1;
+        }
+        for (;;) {
+            bool live = false;
+#pragma unroll
+            for (int e = 0; e < 9; e++) live |= q[e] >= 0;
+            if (!live) break;
+            double4 o[9];
+#pragma unroll
+            for (int e = 0; e < 9; e++)
+                if (q[e] >= 0) o[e] = B.rec[q[e]];
+#pragma unroll
+            for (int e = 0; e < 9; e++)
+                if (q[e] >= 0) {
+                    const double ex = o[e].x - me.x, ey = o[e].y - me.y, ez = o[e].z - me.z;
+                    if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q[e]);
+                    q[e] = amc_rec_next(o[e]);
+                }
+        }
     }
     const unsigned long long found = __ballot(my_k >= 0);
     if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);

@@ -150,6 +150,13 @@ def main():
         engines = [eng]
     elif world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
+        if args.sorted_ic:                              # experiment: storage order = detection-grid order
+            x, y, z = (np.asarray(a) for a in init[:3])
+            h = max(((np.ptp(x) * np.ptp(y) * np.ptp(z)) / max(1, len(x))) ** (1.0 / 3.0), 1e-30)
+            key = (np.floor((z - z.min()) / h).astype(np.int64) * 100000 + np.floor((y - y.min()) / h).astype(np.int64)) * 100000 \
+                + np.floor((x - x.min()) / h).astype(np.int64)
+            order = np.argsort(key, kind="stable")
+            init = tuple(np.asarray(a)[order] for a in init)
         eng = Engine(p)
         eng.set_stream(stream_ptr)
         eng.upload(*init)
