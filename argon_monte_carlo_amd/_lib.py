@@ -57,6 +57,7 @@ SIGNATURES = {
     "amc_mg_unpack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
     "amc_mg_resolve_round": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_mg_commit": (C.c_int, [_ctx]),
+    "amc_mg_bounds": (C.c_int, [_ctx]),
     "amc_mg_finish": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_profile": (C.c_int, [_ctx, C.c_int]),
     "amc_kernel_times": (C.c_int, [_ctx, _dp, _i64p]),

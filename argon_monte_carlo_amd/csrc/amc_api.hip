@@ -932,11 +932,21 @@ int amc_mg_commit(amc_ctx *c)
     return AMC_OK;
 }
 
+int amc_mg_bounds(amc_ctx *c)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));        // Temp:804 on the owned range, counters read later
+    return AMC_OK;
+}
+
 int amc_mg_finish(amc_ctx *c, amc_step_stats *out)
 {
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
-    if (c->P.geometry == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));
+    if (c->P.geometry == AMC_GEOM_PORE || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
+        AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));                     // Pore:550 / Temp:844
     c->out.step++;
     if (!out) return AMC_OK;        // asynchronous: the caller reads the counters later
     return finish_stats(c, out);

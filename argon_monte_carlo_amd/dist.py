@@ -90,6 +90,22 @@ class TorchComm:
         self.dist.all_reduce(t, group=self.group)
         return [int(v) for v in t.cpu().tolist()]
 
+    def allgather_var(self, rows):
+        """all-gather of float64 row blocks of different lengths: list of the blocks of all ranks, in rank order."""
+        import torch
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        if self.world == 1 and self.shortcut:
+            return [rows]
+        counts = [0] * self.world
+        counts[self.rank] = rows.shape[0]
+        counts = self.allreduce_sum_ints(counts)
+        width = rows.shape[1]
+        if sum(counts) == 0:
+            return [rows[:0].copy() for _ in counts]
+        ranges = [(0, c * width) for c in counts]
+        parts = self.gather_shards(torch.from_numpy(rows.reshape(-1)), ranges)
+        return [p.numpy().reshape(-1, width) for p in parts]
+
     def allgather_rows(self, t_full, n, world):
         """all-gather of an arbitrary per-particle tensor (used by download(), not on the hot path)."""
         self.allgather_inplace(t_full, n, world)
@@ -129,8 +145,12 @@ class ShardedSimulation:
         self.engine.mg_unpack(particles)
 
     def timestep(self, dt, reduce_stats=True, want_stats=True):
+        self.engine.mg_local(dt)
+        return self._sweep(reduce_stats, want_stats)
+
+    def _sweep(self, reduce_stats=True, want_stats=True):
+        """positions of all shards -> everybody, detection on the whole system, ordered resolve, per-step counters"""
         e = self.engine
-        e.mg_local(dt)
         for t in e.position_tensors():
             self.comm.allgather_inplace(t, self.n, self.world)
         ncand = e.mg_detect()
@@ -192,3 +212,55 @@ class ShardedSimulation:
             return counts, tot
         flat = self.comm.allreduce_sum_ints(list(counts.astype(np.int64).ravel()) + [int(tot)])
         return np.array(flat[:-1], dtype=np.uint64).reshape(counts.shape), flat[-1]
+
+
+class _GlobalWallHooks:
+    """``drive_energised_cases`` hooks over all shards: the hits of a case are concatenated in rank order — ascending
+    particle index, the order of the reference's ``np.where(hits)`` loop (Temp:132-152, 311-553) — on every rank, so
+    every rank draws the same random directions from identically seeded streams and applies its own slice."""
+
+    def __init__(self, engine, comm, rank):
+        self.e, self.comm, self.rank = engine, comm, rank
+
+    def wall_hits(self, case):
+        idx, normals, contact_z, ok = self.e.wall_hits(case)
+        mine = np.column_stack([idx.astype(np.float64), normals.reshape(-1, 3), contact_z, ok.astype(np.float64)])
+        parts = self.comm.allgather_var(mine.reshape(-1, 6))
+        self._off = sum(len(p) for p in parts[:self.rank])
+        self._cnt = len(parts[self.rank])
+        allr = np.concatenate(parts) if parts else mine
+        return allr[:, 0].astype(np.int32), allr[:, 1:4].copy(), allr[:, 4].copy(), allr[:, 5] != 0.0
+
+    def wall_apply(self, case, dirs, Es):
+        a, b = self._off, self._off + self._cnt
+        dpz, dE = self.e.wall_apply(case, np.asarray(dirs)[a:b], np.asarray(Es)[a:b])
+        parts = self.comm.allgather_var(np.column_stack([dpz, dE]).reshape(-1, 2))
+        allr = np.concatenate(parts)
+        return allr[:, 0].copy(), allr[:, 1].copy()
+
+
+class ShardedTemperatureSimulation(ShardedSimulation):
+    """Temperature_Pore_MC.py's step (Temp:662-853) over index-range shards.  ``sampler`` / ``energies`` are the host
+    objects of argon_monte_carlo_amd.energised; every rank must construct them with the same seeds."""
+
+    def __init__(self, params, rank, world, backend="nccl", stream_ptr=None, engine=None, comm=None):
+        if engine is None:
+            from .engine import ShardEnergisedEngine
+            lo, hi = shard_range(int(params.n), rank, world)
+            params.reserved0 |= 1                   # the energised masks read prior_*_vals
+            engine = ShardEnergisedEngine(params, lo, hi)
+            if stream_ptr is None:
+                import torch
+                stream_ptr = torch.cuda.current_stream().cuda_stream
+            engine.set_stream(stream_ptr)
+        super().__init__(params, rank, world, backend=backend, stream_ptr=stream_ptr, engine=engine, comm=comm)
+        self._hooks = _GlobalWallHooks(self.engine, self.comm, self.rank)
+
+    def temp_timestep(self, dt, sampler, energies, reduce_stats=True):
+        from .energised import drive_energised_cases
+        e = self.engine
+        e.temp_begin(dt)                                                # drift + specular cases on the shard
+        res = drive_energised_cases(self._hooks, sampler, energies)     # the seven energised cases, global RNG order
+        e.mg_bounds()                                                   # Temp:804
+        st = self._sweep(reduce_stats, True)                            # Temp:813-844
+        return (st,) + res

@@ -281,3 +281,11 @@ class EnergisedEngine(Engine):
         res = drive_energised_cases(self, sampler, energies)
         st = self.temp_end()
         return (st,) + res
+
+
+class ShardEnergisedEngine(ShardEngine, EnergisedEngine):
+    """Energised walls on a shard: ``temp_begin`` / ``wall_hits`` / ``wall_apply`` act on the owned index range,
+    ``mg_bounds`` is the bounds check between the walls and the sweep (Temp:804); the sweep is ShardEngine's."""
+
+    def mg_bounds(self):
+        self._ck(self.lib.amc_mg_bounds(self._ctx))

@@ -94,6 +94,11 @@ def main():
     ap.add_argument("--sorted-ic", action="store_true", help="experiment: upload the particles in spatial (cell) order")
     ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
     args = ap.parse_args()
+    # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner at communicator
+    # creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -129,14 +134,18 @@ def main():
         import random
         from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
         from argon_monte_carlo_amd.engine import EnergisedEngine
-        if world != 1:
-            raise SystemExit("the energised-wall workload is single-GPU (host RNG hand-over per step)")
-        p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
+        sharded = world > 1 or args.force_sharded
+        n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
+        p, c, init = make_workload(args.workload, n_total, device=local_rank)
         p.reserved0 |= 1
-        eng = EnergisedEngine(p)
-        eng.set_stream(stream_ptr)
+        if sharded:
+            from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
+            eng = ShardedTemperatureSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
+        else:
+            eng = EnergisedEngine(p)
+            eng.set_stream(stream_ptr)
         eng.upload(*init)
-        sampler = DirectionSampler(np.random.RandomState(17), random.Random(17))
+        sampler = DirectionSampler(np.random.RandomState(17), random.Random(17))     # same streams on every rank
         energies = SurfaceEnergies(c)
 
         def step(k):
@@ -145,9 +154,9 @@ def main():
                 st = eng.temp_timestep(c["dt"], sampler, energies)[0]
                 tot = st if tot is None else {kk: tot[kk] + st[kk] for kk in st}
             return tot
-        n_total = int(p.n)
-        parallelism = "single GPU + host RNG/mpmath hand-over per energised case"
-        engines = [eng]
+        parallelism = ("single GPU" if not sharded else f"index-range shards x{world}, hits concatenated in index order, "
+                       "per-step all-gather of positions (RCCL)") + " + host RNG/mpmath hand-over per energised case"
+        engines = [eng.engine if sharded else eng]
     elif world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
         if args.sorted_ic:                              # experiment: storage order = detection-grid order
@@ -226,7 +235,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and kind != "temp":
             out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -235,6 +235,10 @@ int amc_reset_outputs(amc_ctx *ctx);
  *                           before the next round, so every rank emulates every cluster on identical inputs)
  *   amc_mg_commit           results -> particle arrays (every rank applies all of them; owners stay authoritative)
  *   amc_mg_finish           bounds check after the sweep on [lo,hi), step counter, per-step counters
+ * Energised walls (Temp:662-853) shard the same way: amc_temp_begin / amc_wall_hits / amc_wall_apply act on [lo,hi);
+ * the host concatenates the hits of all ranks in rank order (= ascending particle index) before drawing the random
+ * directions, so every rank consumes the two RNG streams identically.  amc_mg_bounds is the bounds
+ * check between the walls and the sweep (Temp:804) on [lo,hi) without a counter read-back; the sweep then runs as above.
  * No data-path collective other than the position all-gather and the small state tables. */
 int amc_set_shard(amc_ctx *ctx, int64_t lo, int64_t hi);
 typedef struct amc_device_view {
@@ -253,6 +257,7 @@ int amc_mg_unpack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
  * (another round is needed); new_members receives the particles pulled in by validation (ascending). */
 int amc_mg_resolve_round(amc_ctx *ctx, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new);
 int amc_mg_commit(amc_ctx *ctx);
+int amc_mg_bounds(amc_ctx *ctx);
 int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no host synchronisation (counters stay on the device) */
 
 /* ---- measurement ----------------------------------------------------------------------------------------- */

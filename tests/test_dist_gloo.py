@@ -119,6 +119,33 @@ class NumpyShardEngine:
             for k in ("vx", "vy", "vz"):
                 self.a[k][p] = self.vnew[k][p]
 
+    # -- energised-wall hooks (fake rules; the point is the global ordering of hits and of the RNG draws)
+    def temp_begin(self, dt):
+        self.mg_local(dt)
+        self.step = getattr(self, "step", 0) + 1
+
+    def wall_hits(self, case):
+        own = np.arange(self.lo, self.hi)
+        hit = own[(own * 7 + case * 3 + self.step) % 11 == 0]
+        nm = np.zeros((len(hit), 3))
+        nm[:, case % 3] = 1.0 if case % 2 else -1.0
+        ok = (hit % 5) != 0                                        # some contact solves "fail": no RNG draw for them
+        self._hit = hit
+        return hit.astype(np.int32), nm, self.a["z"][hit].copy(), ok
+
+    def wall_apply(self, case, dirs, Es):
+        hit = self._hit
+        assert len(dirs) == len(hit) == len(Es)
+        sp = np.sqrt(self.a["vx"][hit] ** 2 + self.a["vy"][hit] ** 2 + self.a["vz"][hit] ** 2)
+        assert not np.isnan(sp).any()
+        old_vz = self.a["vz"][hit].copy()
+        for k, v in enumerate(("vx", "vy", "vz")):
+            self.a[v][hit] = np.asarray(dirs)[:, k] * sp
+        return old_vz - self.a["vz"][hit], np.asarray(Es) * sp
+
+    def mg_bounds(self):
+        pass
+
     def mg_finish(self, want_stats=True):
         return dict(n_pp=len(self.cand[0]) if self.lo == 0 else 0, n_wall=self.hi - self.lo, n_oob_walls=0, n_oob_pp=0,
                     n_paths=0, n_candidates=len(self.cand[0]), n_clusters=0, n_rounds=self.round, n_fp_errors=0, flags=0)
@@ -205,3 +232,65 @@ def test_shard_ranges_cover_everything():
             r = [shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+
+
+# ---- energised walls over shards: global hit order and RNG consumption ---------------------------------------------------------
+class _Energies:
+    cold, hot = 1.0e-21, 2.0e-21
+
+    def gap(self, z):
+        return 1.5e-21 + z
+
+
+def run_temp(n, rank, world, steps, comm):
+    import random
+    from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
+    from argon_monte_carlo_amd.energised import DirectionSampler
+    p, _ = PR.cube_params(n=n)
+    lo, hi = shard_range(n, rank, world)
+    sim = ShardedTemperatureSimulation(p, rank, world, engine=NumpyShardEngine(n, lo, hi, 3.385137501286538e-10), comm=comm)
+    sim.upload(*make_state(n, seed=9))
+    sampler = DirectionSampler(np.random.RandomState(3), random.Random(3))
+    out = []
+    for s in range(steps):
+        st, mom, cold, hot, hm, hc, hh = sim.temp_timestep(2e-13, sampler, _Energies())
+        out.append((float(mom), float(cold), float(hot), hm, hc, hh, st["n_pp"]))
+    return sim, out
+
+
+def _temp_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sim, out = run_temp(n, rank, world, steps, TorchComm(rank, world))
+        full = sim.download()
+        if rank == 0:
+            q.put((full, out))
+    finally:
+        dist.destroy_process_group()
+
+
+class _NoCommVar(_NoComm):
+    def allgather_var(self, rows):
+        return [np.ascontiguousarray(rows, dtype=np.float64)]
+
+
+def test_energised_walls_two_ranks_equal_one_rank():
+    n, steps = 251, 5
+    ref_sim, ref_out = run_temp(n, 0, 1, steps, _NoCommVar())
+    ref = ref_sim.engine.download()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_temp_worker, args=(r, 2, port, n, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert any(o[3] for o in ref_out)                                          # wall hits happened
+    assert out == ref_out                                                       # per-step momentum / energy sums, bitwise
+    for k in KEYS:
+        assert np.array_equal(got[k].view(np.int64), ref[k].view(np.int64)), k

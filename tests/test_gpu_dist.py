@@ -77,3 +77,69 @@ def test_two_ranks_one_gpu_equal_single_engine(kind, n, steps):
     for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
         assert tot[k] == ref_tot[k], (k, tot, ref_tot)
     assert npaths == ref_npaths and np.array_equal(counts, ref_counts)
+
+
+# ---- energised walls (Temperature_Pore_MC.py) over two shards ---------------------------------------------------------------------
+def _temp_case(n):
+    from argon_monte_carlo_amd import ic as IC, params as PR
+    p, c = PR.pore_params(n=n, energised=True)
+    init = IC.pore_ic(p, c, seed=23)
+    p.detect_mode = 1
+    p.reserved0 |= 1
+    return p, c, init
+
+
+def _temp_objects(c):
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+    return DirectionSampler(np.random.RandomState(5), random.Random(5)), SurfaceEnergies(c)
+
+
+def _temp_worker(rank, world, port, n, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
+        p, c, init = _temp_case(n)
+        sim = ShardedTemperatureSimulation(p, rank, world, backend="gloo")
+        sim.upload(*init)
+        sampler, energies = _temp_objects(c)
+        rows = []
+        for s in range(steps):
+            st, mom, cold, hot, hm, hc, hh = sim.temp_timestep(c["dt"], sampler, energies)
+            rows.append((float(mom), float(cold), float(hot), hm, hc, hh, st["n_pp"], st["n_wall"], st["n_oob_walls"], st["n_oob_pp"]))
+        full = sim.download()
+        if rank == 0:
+            q.put((full, rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_energised_walls_two_ranks_one_gpu_equal_single_engine():
+    from argon_monte_carlo_amd.engine import EnergisedEngine
+    n, steps = 200000, 5
+    p, c, init = _temp_case(n)
+    eng = EnergisedEngine(p)
+    eng.upload(*init)
+    sampler, energies = _temp_objects(c)
+    ref_rows = []
+    for s in range(steps):
+        st, mom, cold, hot, hm, hc, hh = eng.temp_timestep(c["dt"], sampler, energies)
+        ref_rows.append((float(mom), float(cold), float(hot), hm, hc, hh, st["n_pp"], st["n_wall"], st["n_oob_walls"], st["n_oob_pp"]))
+    ref = eng.download()
+    eng.close()
+    assert sum(r[7] for r in ref_rows) > 0 and sum(r[6] for r in ref_rows) > 0      # wall hits and p-p collisions happened
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_temp_worker, args=(r, 2, port, n, steps, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    full, rows = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert rows == ref_rows, (rows, ref_rows)
+    for k in KEYS:
+        assert np.array_equal(full[k], ref[k]), (k, np.flatnonzero(full[k] != ref[k])[:5])
