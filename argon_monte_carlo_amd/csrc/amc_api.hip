@@ -176,6 +176,7 @@ void amc_destroy(amc_ctx *c)
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
+    if (c->h_pin) hipHostFree(c->h_pin);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -220,7 +221,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->mg_ncand = 0;
-    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr;
+    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0;
     c->stream = nullptr;
     int rc = AMC_OK;
 #define CK(call)                                                                                       \
@@ -320,6 +321,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
                 c->d_host_ncand = (int *)dp;
             }
         }
+        c->h_pin_bytes = (size_t)4 << 20;
+        if (hipHostMalloc((void **)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; c->h_pin_bytes = 0; }
         if (getenv("AMC_DEBUG_RESOLVE")) {
             CK(dalloc(&c->d_dbg, 16));
             CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 16, c->stream));
@@ -411,10 +414,40 @@ int amc_download_prior(amc_ctx *c, double *px, double *py, double *pz)
 }
 
 // ---- the step ----------------------------------------------------------------------------------------------------------
+// Small device -> host read-backs go through the pinned staging buffer: queue any number of pieces, synchronise once,
+// then copy out.  (Falls back to direct copies when a piece does not fit.)
+struct amc_stage {
+    amc_ctx *c;
+    size_t off = 0;
+    struct piece { void *dst; size_t off, bytes; };
+    std::vector<piece> pieces;
+    explicit amc_stage(amc_ctx *ctx) : c(ctx) {}
+    hipError_t get(void *dst, const void *src, size_t bytes)
+    {
+        if (!bytes) return hipSuccess;
+        c->mg_prefix = 0;                       // the staging area is being reused
+        const size_t at = (off + 63) & ~(size_t)63;
+        if (!c->h_pin || at + bytes > c->h_pin_bytes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+        pieces.push_back({dst, at, bytes});
+        off = at + bytes;
+        return hipMemcpyAsync(c->h_pin + at, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    hipError_t finish()
+    {
+        const hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess)
+            for (auto &p : pieces) memcpy(p.dst, c->h_pin + p.off, p.bytes);
+        pieces.clear();
+        off = 0;
+        return e;
+    }
+};
+
 static int read_counters(amc_ctx *c, amc_dev_counters *h)
 {
-    AMC_HIP(c, hipMemcpyAsync(h, c->d_cnt, sizeof *h, hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    amc_stage st(c);
+    AMC_HIP(c, st.get(h, c->d_cnt, sizeof *h));
+    AMC_HIP(c, st.finish());
     return AMC_OK;
 }
 
@@ -734,8 +767,9 @@ int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, dou
     amc_temp_ws &T = c->T;
     AMC_HIP(c, amc_launch_temp_hits(c, case_id));
     int cnt = 0;
-    AMC_HIP(c, hipMemcpyAsync(&cnt, T.count, sizeof cnt, hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    amc_stage stg(c);
+    AMC_HIP(c, stg.get(&cnt, T.count, sizeof cnt));
+    AMC_HIP(c, stg.finish());
     if (cnt > T.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits exceed the record capacity %d", cnt, T.cap);
     if ((size_t)cnt > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits, caller buffer holds %zu", cnt, cap);
     T.last_case = case_id; T.last_n = cnt;
@@ -744,9 +778,10 @@ int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, dou
     if (cnt == 0) return AMC_OK;
     std::vector<int> hidx((size_t)cnt);
     std::vector<double> hnorm(3 * (size_t)cnt), hcontact(3 * (size_t)cnt);
-    AMC_HIP(c, hipMemcpy(hidx.data(), T.idx, sizeof(int) * cnt, hipMemcpyDeviceToHost));
-    AMC_HIP(c, hipMemcpy(hnorm.data(), T.normal, sizeof(double) * 3 * cnt, hipMemcpyDeviceToHost));
-    AMC_HIP(c, hipMemcpy(hcontact.data(), T.contact, sizeof(double) * 3 * cnt, hipMemcpyDeviceToHost));
+    AMC_HIP(c, stg.get(hidx.data(), T.idx, sizeof(int) * cnt));
+    AMC_HIP(c, stg.get(hnorm.data(), T.normal, sizeof(double) * 3 * cnt));
+    AMC_HIP(c, stg.get(hcontact.data(), T.contact, sizeof(double) * 3 * cnt));
+    AMC_HIP(c, stg.finish());
     for (int k = 0; k < cnt; k++) T.perm[k] = k;
     std::sort(T.perm.begin(), T.perm.end(), [&](int a, int b) { return hidx[a] < hidx[b]; });   // ascending particle index
     for (int s = 0; s < cnt; s++) {
@@ -779,9 +814,10 @@ int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double 
     AMC_HIP(c, hipMemcpyAsync(T.Es, hEs.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n));
     std::vector<double> hp(n), he(n);
-    AMC_HIP(c, hipMemcpyAsync(hp.data(), T.dpz, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipMemcpyAsync(he.data(), T.dE, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    amc_stage stg(c);
+    AMC_HIP(c, stg.get(hp.data(), T.dpz, sizeof(double) * n));
+    AMC_HIP(c, stg.get(he.data(), T.dE, sizeof(double) * n));
+    AMC_HIP(c, stg.finish());
     for (size_t s = 0; s < n; s++) {
         if (dpz) dpz[s] = hp[T.perm[s]];
         if (dE) dE[s] = he[T.perm[s]];
@@ -849,9 +885,21 @@ int amc_mg_detect(amc_ctx *c, int64_t *n_candidates)
     AMC_HIP(c, hipSetDevice(c->device));
     AMC_HIP(c, amc_launch_bin(c));
     AMC_HIP(c, amc_launch_detect(c));
+    // the counters and the head of the candidate list in one synchronisation (amc_mg_candidates then needs none)
     amc_dev_counters now;
-    int rc = read_counters(c, &now);
-    if (rc) return rc;
+    c->mg_prefix = 0;
+    const int pre = std::min(c->W.max_cand, 8192);
+    if (c->h_pin && c->h_pin_bytes >= 4096 + 2 * sizeof(int) * (size_t)pre) {
+        AMC_HIP(c, hipMemcpyAsync(c->h_pin, c->d_cnt, sizeof now, hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipMemcpyAsync(c->h_pin + 4096, c->W.cand_i, sizeof(int) * (size_t)pre, hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipMemcpyAsync(c->h_pin + 4096 + sizeof(int) * (size_t)pre, c->W.cand_j, sizeof(int) * (size_t)pre, hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipStreamSynchronize(c->stream));
+        memcpy(&now, c->h_pin, sizeof now);
+        c->mg_prefix = pre;
+    } else {
+        int rc = read_counters(c, &now);
+        if (rc) return rc;
+    }
     if (now.cand_count > (unsigned)c->W.max_cand) return amc_fail(c, AMC_ERR_CAPACITY, "candidate list overflow (%u)", now.cand_count);
     if (n_candidates) *n_candidates = now.cand_count;
     c->mg_ncand = (int)now.cand_count;
@@ -864,11 +912,16 @@ int amc_mg_candidates(amc_ctx *c, int32_t *cand_i, int32_t *cand_j, size_t cap, 
     AMC_HIP(c, hipSetDevice(c->device));
     const size_t k = std::min<size_t>((size_t)std::max(c->mg_ncand, 0), (size_t)c->W.max_cand);   // from amc_mg_detect
     if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "amc_mg_candidates: %zu pairs, buffer holds %zu", k, cap);
-    if (k) {
-        AMC_HIP(c, hipMemcpyAsync(cand_i, c->W.cand_i, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream));
-        AMC_HIP(c, hipMemcpyAsync(cand_j, c->W.cand_j, sizeof(int) * k, hipMemcpyDeviceToHost, c->stream));
-        AMC_HIP(c, hipStreamSynchronize(c->stream));
+    if (k && (int)k <= c->mg_prefix) {          // staged by amc_mg_detect
+        memcpy(cand_i, c->h_pin + 4096, sizeof(int) * k);
+        memcpy(cand_j, c->h_pin + 4096 + sizeof(int) * (size_t)c->mg_prefix, sizeof(int) * k);
+    } else if (k) {
+        amc_stage stg(c);
+        AMC_HIP(c, stg.get(cand_i, c->W.cand_i, sizeof(int) * k));
+        AMC_HIP(c, stg.get(cand_j, c->W.cand_j, sizeof(int) * k));
+        AMC_HIP(c, stg.finish());
     }
+    c->mg_prefix = 0;
     *n = k;
     return AMC_OK;
 }
@@ -908,8 +961,9 @@ int amc_mg_resolve_round(amc_ctx *c, int first, int *dirty, int32_t *new_members
     AMC_HIP(c, hipSetDevice(c->device));
     AMC_HIP(c, amc_launch_resolve_round(c, first));
     amc_resolve_ctl ctl;
-    AMC_HIP(c, hipMemcpyAsync(&ctl, c->W.ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    amc_stage stg(c);
+    AMC_HIP(c, stg.get(&ctl, c->W.ctl, sizeof ctl));
+    AMC_HIP(c, stg.finish());
     *dirty = 0; *n_new = 0;
     if (!ctl.active) return AMC_OK;
     if (ctl.ovf) return amc_fail(c, AMC_ERR_CAPACITY, "resolve work space overflow");
@@ -917,7 +971,8 @@ int amc_mg_resolve_round(amc_ctx *c, int first, int *dirty, int32_t *new_members
     const int k = ctl.nslots - ctl.nslots0;
     if (k > 0) {
         if ((size_t)k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d new cluster members, buffer holds %zu", k, cap);
-        AMC_HIP(c, hipMemcpy(new_members, c->W.sl_p + ctl.nslots0, sizeof(int) * (size_t)k, hipMemcpyDeviceToHost));
+        AMC_HIP(c, stg.get(new_members, c->W.sl_p + ctl.nslots0, sizeof(int) * (size_t)k));
+        AMC_HIP(c, stg.finish());
         std::sort(new_members, new_members + k);
         *n_new = (size_t)k;
     }

@@ -131,6 +131,10 @@ struct amc_ctx {
     int *d_host_ncand;             // its device address
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     int mg_ncand;                  // candidate count read back by the last amc_mg_detect
+    // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
+    char *h_pin;
+    size_t h_pin_bytes;
+    int mg_prefix;                 // candidates already staged in h_pin by amc_mg_detect
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
