@@ -177,6 +177,8 @@ void amc_destroy(amc_ctx *c)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->pos_send) hipFree(c->pos_send);
+    if (c->pos_recv) hipFree(c->pos_recv);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -222,6 +224,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->mg_ncand = 0;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0;
+    c->pos_send = c->pos_recv = nullptr; c->pos_world = 0; c->pos_m = 0;
     c->stream = nullptr;
     int rc = AMC_OK;
 #define CK(call)                                                                                       \
@@ -876,6 +879,46 @@ int amc_mg_local(amc_ctx *c, double dt)
     AMC_HIP(c, hipSetDevice(c->device));
     const int st = (c->P.geometry == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
     AMC_HIP(c, amc_launch_stream(c, dt, st, 0));
+    return AMC_OK;
+}
+
+int amc_mg_positions_view(amc_ctx *c, int world, void **send, void **recv, int64_t *m)
+{
+    if (!c || world < 1 || !send || !recv || !m) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (c->pos_world != world) {
+        if (c->pos_send) hipFree(c->pos_send);
+        if (c->pos_recv) hipFree(c->pos_recv);
+        c->pos_send = c->pos_recv = nullptr;
+        c->pos_m = (c->n + world - 1) / world;
+        const size_t mm = (size_t)std::max<int64_t>(c->pos_m, 1);
+        AMC_HIP(c, hipMalloc((void **)&c->pos_send, sizeof(double) * 3 * mm));
+        AMC_HIP(c, hipMalloc((void **)&c->pos_recv, sizeof(double) * 3 * mm * (size_t)world));
+        c->pos_world = world;
+    }
+    *send = c->pos_send; *recv = c->pos_recv; *m = c->pos_m;
+    return AMC_OK;
+}
+
+int amc_mg_pack_positions(amc_ctx *c, int world)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (world != c->pos_world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_positions_view(world=%d) has not been called", world);
+    AMC_HIP(c, hipSetDevice(c->device));
+    // this rank's range must be the driver's shard of that world size (the unpack side recomputes the ranges)
+    AMC_HIP(c, amc_launch_pos_pack(c, world, 0, 0));
+    return AMC_OK;
+}
+
+int amc_mg_unpack_positions(amc_ctx *c, int world, int rank)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (world != c->pos_world || rank < 0 || rank >= world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_unpack_positions: world/rank do not match amc_mg_positions_view");
+    const int64_t base = c->n / world, rem = c->n % world;
+    const int64_t lo = rank * base + std::min<int64_t>(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
+    if (lo != c->lo || hi != c->hi) return amc_fail(c, AMC_ERR_STATE, "rank %d of %d owns [%lld,%lld), amc_set_shard says [%lld,%lld)", rank, world, (long long)lo, (long long)hi, (long long)c->lo, (long long)c->hi);
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_pos_pack(c, world, rank, 1));
     return AMC_OK;
 }
 

@@ -135,6 +135,9 @@ struct amc_ctx {
     char *h_pin;
     size_t h_pin_bytes;
     int mg_prefix;                 // candidates already staged in h_pin by amc_mg_detect
+    double *pos_send, *pos_recv;   // packed position exchange: [3][m] and [world][3][m]
+    int pos_world;
+    int64_t pos_m;
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
@@ -165,6 +168,7 @@ hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
 hipError_t amc_launch_commit(amc_ctx *c);
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
+hipError_t amc_launch_pos_pack(amc_ctx *c, int world, int rank, int unpack);
 hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack);
 // the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
 struct amc_resolve_ctl {

@@ -1043,6 +1043,48 @@ hipError_t amc_launch_commit(amc_ctx *c)
     amc_prof_end(c);
     return hipGetLastError();
 }
+// ---- packed position exchange (one all-gather per step): send = [3][m], recv = [world][3][m] ---------------------------
+__global__ __launch_bounds__(256) void k_pos_pack(const double *__restrict__ x, const double *__restrict__ y,
+                                                  const double *__restrict__ z, long long lo, long long hi, long long m,
+                                                  double *__restrict__ send)
+{
+    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= m) return;
+    const bool in = lo + u < hi;
+    send[u] = in ? x[lo + u] : 0.0;
+    send[m + u] = in ? y[lo + u] : 0.0;
+    send[2 * m + u] = in ? z[lo + u] : 0.0;
+}
+__global__ __launch_bounds__(256) void k_pos_unpack(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                                                    long long n, int world, int rank, long long m,
+                                                    const double *__restrict__ recv)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)world * m) return;
+    const int r = (int)(idx / m);
+    const long long u = idx % m;
+    if (r == rank) return;                                  // my own shard is already in place
+    const long long base = n / world, rem = n % world;
+    const long long lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
+    if (u >= cnt) return;
+    const double *blk = recv + (size_t)r * 3 * (size_t)m;
+    x[lo + u] = blk[u];
+    y[lo + u] = blk[m + u];
+    z[lo + u] = blk[2 * m + u];
+}
+hipError_t amc_launch_pos_pack(amc_ctx *c, int world, int rank, int unpack)
+{
+    const long long m = c->pos_m;
+    if (m <= 0) return hipSuccess;
+    if (!unpack)
+        hipLaunchKernelGGL(k_pos_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z,
+                           (long long)c->lo, (long long)c->hi, m, c->pos_send);
+    else
+        hipLaunchKernelGGL(k_pos_unpack, dim3((unsigned)(((long long)world * m + 255) / 256)), dim3(256), 0, c->stream, c->S.x,
+                           c->S.y, c->S.z, (long long)c->n, world, rank, m, c->pos_recv);
+    return hipGetLastError();
+}
+
 hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack)
 {
     if (n <= 0) return hipSuccess;

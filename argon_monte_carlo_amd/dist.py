@@ -59,6 +59,20 @@ class TorchComm:
             for r, (a, b) in enumerate(ranges):
                 self.dist.broadcast(full[a:b], src=r, group=self.group)
 
+    def allgather_packed(self, send, recv):
+        """recv = concatenation of every rank's `send` (equal sizes), in rank order."""
+        if self.world == 1 and self.shortcut:
+            recv.copy_(send)
+            return
+        if self._stage(send):
+            import torch
+            h = send.cpu()
+            parts = [torch.empty_like(h) for _ in range(self.world)]
+            self.dist.all_gather(parts, h, group=self.group)
+            recv.copy_(torch.cat(parts))
+        else:
+            self.dist.all_gather_into_tensor(recv, send, group=self.group)
+
     def gather_shards(self, mine, ranges):
         """all-gather of (possibly unequal) host shards: padded to the longest one."""
         import torch
@@ -151,8 +165,15 @@ class ShardedSimulation:
     def _sweep(self, reduce_stats=True, want_stats=True):
         """positions of all shards -> everybody, detection on the whole system, ordered resolve, per-step counters"""
         e = self.engine
-        for t in e.position_tensors():
-            self.comm.allgather_inplace(t, self.n, self.world)
+        if hasattr(e, "mg_pack_positions") and hasattr(self.comm, "allgather_packed"):
+            if not (self.world == 1 and self.comm.shortcut):
+                send, recv = e.packed_positions(self.world)          # one collective for x, y and z
+                e.mg_pack_positions(self.world)
+                self.comm.allgather_packed(send, recv)
+                e.mg_unpack_positions(self.world, self.rank)
+        else:
+            for t in e.position_tensors():
+                self.comm.allgather_inplace(t, self.n, self.world)
         ncand = e.mg_detect()
         rounds = 0
         if ncand:

@@ -198,6 +198,22 @@ class ShardEngine(Engine):
             self._xchg_t = self._wrap(self._view.xchg, 11 * int(self._view.xchg_capacity), "<i8")
         return self._xchg_t[: 11 * int(n_particles)]
 
+    def packed_positions(self, world):
+        """(send, recv) tensors of the packed position exchange: float64[3*m] and float64[world*3*m]."""
+        if getattr(self, "_pp_world", None) != world:
+            send, recv, m = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+            self._ck(self.lib.amc_mg_positions_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(m)))
+            mm = max(1, m.value)
+            self._pp = (self._wrap(send.value, 3 * mm, "<f8"), self._wrap(recv.value, 3 * mm * world, "<f8"))
+            self._pp_world = world
+        return self._pp
+
+    def mg_pack_positions(self, world):
+        self._ck(self.lib.amc_mg_pack_positions(self._ctx, int(world)))
+
+    def mg_unpack_positions(self, world, rank):
+        self._ck(self.lib.amc_mg_unpack_positions(self._ctx, int(world), int(rank)))
+
     def mg_local(self, dt):
         self._ck(self.lib.amc_mg_local(self._ctx, float(dt)))
 

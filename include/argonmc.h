@@ -249,6 +249,13 @@ typedef struct amc_device_view {
 } amc_device_view;
 int amc_device_view_get(amc_ctx *ctx, amc_device_view *out);
 int amc_mg_local(amc_ctx *ctx, double dt);
+/* Packed form of the position all-gather (one collective per step instead of three).  With m = ceil(n / world):
+ * send = float64[3][m], this rank's x|y|z shard (zero padded); recv = float64[world][3][m], the send blocks of all
+ * ranks in rank order (the output of an all-gather of `send`).  Shards follow the driver's rule: rank r owns
+ * base + (r < n % world) particles starting at r * base + min(r, n % world), base = n / world. */
+int amc_mg_positions_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *m);
+int amc_mg_pack_positions(amc_ctx *ctx, int world);
+int amc_mg_unpack_positions(amc_ctx *ctx, int world, int rank);
 int amc_mg_detect(amc_ctx *ctx, int64_t *n_candidates);
 int amc_mg_candidates(amc_ctx *ctx, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n);
 int amc_mg_pack_state(amc_ctx *ctx, const int32_t *particles, size_t n);

@@ -39,8 +39,10 @@ steps = 200
 t_all = time.perf_counter()
 for s in range(steps):
     timed("mg_local", e.mg_local, c["dt"])
-    for t in e.position_tensors():
-        timed("allgather", sim.comm.allgather_inplace, t, sim.n, sim.world)
+    send, recv = e.packed_positions(sim.world)
+    timed("pos_pack", e.mg_pack_positions, sim.world)
+    timed("allgather", sim.comm.allgather_packed, send, recv)
+    timed("pos_unpack", e.mg_unpack_positions, sim.world, sim.rank)
     ncand = timed("mg_detect", e.mg_detect)
     if ncand:
         ci, cj = timed("mg_candidates", e.mg_candidates, ncand)
