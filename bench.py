@@ -68,11 +68,18 @@ def cpu_baseline(workload, budget_s=12.0):
     p, c, init = make_workload(workload)
     orc = O.Oracle(p, mode="mul")
     orc.upload(*init)
-    orc.timestep(c["dt"])                       # warm-up (page faults)
+    if WORKLOADS[workload][0] == "temp":
+        import random
+        from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+        sampler, energies = DirectionSampler(np.random.RandomState(17), random.Random(17)), SurfaceEnergies(c)
+        one = lambda: orc.temp_timestep(c["dt"], sampler, energies)     # noqa: E731
+    else:
+        one = lambda: orc.timestep(c["dt"])                             # noqa: E731
+    one()                                       # warm-up (page faults)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        orc.timestep(c["dt"])
+        one()
         steps += 1
         el = time.perf_counter() - t0
         if el > budget_s or steps >= 2000:
@@ -81,8 +88,26 @@ def cpu_baseline(workload, budget_s=12.0):
             "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle/amc_oracle.c single thread"}
 
 
+def committed_traffic(workload, kclass, tag):
+    """HBM bytes per launch of the dominant kernel from the committed counter passes (profiles/<round>_pmc_traffic_*.json,
+    produced by tools/collect_profiles.sh + tools/summarise_profiles.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate runs).  bench.py itself cannot read PMC counters; None when no pass exists for this workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{tag}_pmc_traffic_{workload}.json")
+    if not os.path.exists(path):
+        return None, None
+    needle = {"resolve": "k_resolve<", "detect": "k_detect_lists", "drift_walls": "k_stream", "validate": "k_validate",
+              "commit": "k_commit"}.get(kclass)
+    kern = json.load(open(path)).get("kernels", {})
+    for name, v in kern.items():
+        if needle and needle in name and (kclass != "resolve" or name.rstrip().endswith("0>")) and "bounds-only" not in name:
+            kib = v.get("FETCH_SIZE_KiB_avg", 0.0) + v.get("WRITE_SIZE_KiB_avg", 0.0)
+            return kib * 1024.0, f"profiles/{os.path.basename(path)}: {name} (FETCH_SIZE + WRITE_SIZE, uncorrected)"
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--round-tag", default="r01", help="prefix of the committed profile files to take `traffic` from")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
@@ -224,6 +249,8 @@ def main():
                     "algorithmic_bytes_per_launch": per_particle * units,
                     "per_kernel_avg_us": {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]},
                     "whole_step_frac_of_hbm_peak": BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
+        if roof is not None:
+            roof["traffic"], roof["traffic_source"] = committed_traffic(args.workload, roof["kernel_class"], args.round_tag)
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
@@ -233,7 +260,7 @@ def main():
                        "pp_collisions_per_step": stats["n_pp"] / args.steps if stats else None},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and kind != "temp":
+        if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
