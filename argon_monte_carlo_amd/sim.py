@@ -107,6 +107,8 @@ class Simulation:
     def histograms(self):
         """(densities dict, bin edges) from the histograms accumulated on the device."""
         counts, _ = self.engine.histograms()
+        if getattr(self, "_hist_base", None) is not None:
+            counts = counts + self._hist_base          # paths completed before the checkpoint this run resumed from
         dens = {}
         edges = None
         for row, key in enumerate(["total", "x", "y", "z"]):
@@ -116,6 +118,47 @@ class Simulation:
     def write_outputs(self, directory="."):
         dens, edges = self.histograms()
         OUT.write_histograms(directory, dens, edges)
+
+    # ---- checkpoint / resume (the reference has none: a 10^4-step run is one process lifetime there) ---------------
+    def _checkpoint_extra(self):
+        return {}
+
+    def _restore_extra(self, z):
+        pass
+
+    def save_checkpoint(self, path):
+        """Everything a later ``load_checkpoint`` needs to continue bit-identically: the particle arrays, the
+        completed-path lists, the device histograms and the counters (+ RNG streams and per-step lists for Temp)."""
+        st = self.engine.download()
+        self._collect()
+        counts, _ = self.engine.histograms()
+        base = getattr(self, "_hist_base", None)
+        if base is not None:
+            counts = counts + base
+        np.savez(path, kind=self.kind, n=int(self.params.n), collision_range=float(self.params.collision_range),
+                 hist_counts=counts.astype(np.uint64), completed_paths=np.array(self.completed_paths, dtype=np.float64),
+                 completed_x_paths=np.array(self.completed_x_paths, dtype=np.float64),
+                 completed_y_paths=np.array(self.completed_y_paths, dtype=np.float64),
+                 completed_z_paths=np.array(self.completed_z_paths, dtype=np.float64),
+                 total_cols=int(self.total_cols), steps_done=int(self.steps_done),
+                 **{f"state_{k}": v for k, v in st.items()}, **self._checkpoint_extra())
+
+    def load_checkpoint(self, path):
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz", allow_pickle=False)
+        if str(z["kind"]) != self.kind or int(z["n"]) != int(self.params.n) or \
+                float(z["collision_range"]) != float(self.params.collision_range):
+            raise ValueError("checkpoint was written by a different configuration")
+        self.engine.upload(*[z[f"state_{k}"] for k in ("x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz")],
+                           flag=z["state_flag"])
+        self.engine.reset_outputs()
+        self._hist_base = z["hist_counts"].astype(np.uint64)
+        self.completed_paths = z["completed_paths"].tolist()
+        self.completed_x_paths = z["completed_x_paths"].tolist()
+        self.completed_y_paths = z["completed_y_paths"].tolist()
+        self.completed_z_paths = z["completed_z_paths"].tolist()
+        self.total_cols, self.steps_done = int(z["total_cols"]), int(z["steps_done"])
+        self._cache = None
+        self._restore_extra(z)
 
     def close(self):
         self.engine.close()
@@ -173,6 +216,27 @@ class TemperatureSimulation(Simulation):
     def run(self, nsteps, dt=None):
         for _ in range(int(nsteps)):
             self.timestep(dt, collect_paths=False)
+
+    def _checkpoint_extra(self):
+        np_state = self.sampler.np_rng.get_state()
+        py_state = self.sampler.py_rng.getstate()
+        return dict(momentum=np.array([float(v) for v in self.momentum_z_change_per_step]),
+                    energy_cold=np.array([float(v) for v in self.energy_transfer_cold_per_step]),
+                    energy_hot=np.array([float(v) for v in self.energy_transfer_hot_per_step]),
+                    zero_flags=np.array(self._zero_flags, dtype=bool).reshape(-1, 3), total_errs=int(self.total_errs),
+                    np_rng_keys=np.asarray(np_state[1], dtype=np.uint32),
+                    np_rng_rest=np.array([np_state[2], np_state[3]], dtype=np.int64), np_rng_gauss=float(np_state[4]),
+                    py_rng_state=np.array(py_state[1], dtype=np.uint64), py_rng_version=int(py_state[0]))
+
+    def _restore_extra(self, z):
+        self.momentum_z_change_per_step = z["momentum"].tolist()
+        self.energy_transfer_cold_per_step = z["energy_cold"].tolist()
+        self.energy_transfer_hot_per_step = z["energy_hot"].tolist()
+        self._zero_flags = [tuple(bool(b) for b in row) for row in z["zero_flags"]]
+        self.total_errs = int(z["total_errs"])
+        self.sampler.np_rng.set_state(("MT19937", z["np_rng_keys"], int(z["np_rng_rest"][0]), int(z["np_rng_rest"][1]),
+                                       float(z["np_rng_gauss"])))
+        self.sampler.py_rng.setstate((int(z["py_rng_version"]), tuple(int(v) for v in z["py_rng_state"]), None))
 
     def write_outputs(self, directory="."):
         import os

@@ -504,3 +504,60 @@ def test_candidate_overflow_is_reported_not_silent(Engine):
         eng.timestep(1e-14)
     assert ei.value.code == -4
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- checkpoint / resume
+def test_checkpoint_resume_continues_bit_identically(golden_dir, tmp_path):
+    """save_checkpoint / load_checkpoint: a run interrupted and resumed in a new context ends in the same
+    state, completed-path lists, histograms — and, for Temp, the same momentum_energy.csv — as the uninterrupted one."""
+    import random
+    from argon_monte_carlo_amd import params as PR2
+    from argon_monte_carlo_amd.sim import Simulation, TemperatureSimulation
+    Gs = load_step(golden_dir, "step_temp_a.npz")
+    sigma = 3.6 * 10**(-19) * float(Gs["meta_sigma_mult"])
+    init = [Gs[f"s-001_{k}"] for k in STATE_KEYS]
+    dt = float(Gs["dt"])
+    nsteps, cut = Gs["per_step"].shape[0], Gs["per_step"].shape[0] // 2
+
+    def make(kind):
+        if kind == "temp":
+            p, consts = PR2.pore_params(n=int(Gs["meta_K"]), sigma=sigma, energised=True)
+            return TemperatureSimulation(params=p, consts=consts, np_rng=np.random.RandomState(3), py_rng=random.Random(3))
+        p, consts = PR2.pore_params(n=int(Gs["meta_K"]), sigma=sigma)
+        return Simulation("pore", params=p, consts=consts)
+
+    for kind in ("pore", "temp"):
+        ref = make(kind)
+        ref.set_state(*init)
+        for s in range(nsteps):
+            ref.timestep(dt)
+        a = make(kind)
+        a.set_state(*init)
+        for s in range(cut):
+            a.timestep(dt, collect_paths=(s % 2 == 0))          # some records are still on the device at the checkpoint
+        ck = str(tmp_path / f"ck_{kind}.npz")
+        a.save_checkpoint(ck)
+        a.close()
+        b = make(kind)                                           # fresh context, fresh RNG objects
+        b.load_checkpoint(ck)
+        for s in range(cut, nsteps):
+            b.timestep(dt)
+        for name in ("x_vals", "y_vals", "z_vals", "x_velocities", "y_velocities", "z_velocities", "dist_since_collision",
+                     "dist_x_since_collision", "dist_y_since_collision", "dist_z_since_collision", "full_path_traveled"):
+            assert np.array_equal(getattr(b, name), getattr(ref, name)), (kind, name)
+        assert len(ref.completed_paths) > 0
+        for name in ("completed_paths", "completed_x_paths", "completed_y_paths", "completed_z_paths"):
+            assert getattr(b, name) == getattr(ref, name), (kind, name)
+        assert b.total_cols == ref.total_cols and b.steps_done == ref.steps_done
+        hb, hr = b.histograms()[0], ref.histograms()[0]
+        for k in hr:
+            assert np.array_equal(hb[k], hr[k]), (kind, k)
+        if kind == "temp":
+            os.makedirs(tmp_path / "b", exist_ok=True)
+            os.makedirs(tmp_path / "r", exist_ok=True)
+            b.write_outputs(str(tmp_path / "b"))
+            ref.write_outputs(str(tmp_path / "r"))
+            assert open(tmp_path / "b" / "momentum_energy.csv", "rb").read() == open(tmp_path / "r" / "momentum_energy.csv", "rb").read()
+            assert any(float(v) != 0.0 for v in ref.momentum_z_change_per_step)
+        b.close()
+        ref.close()
