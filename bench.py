@@ -184,12 +184,19 @@ def main():
         engines = [eng.engine if sharded else eng]
     elif world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)
-        if args.sorted_ic:                              # experiment: storage order = detection-grid order
+        if args.sorted_ic:                              # experiment: storage order = the detection grid's cell order
             x, y, z = (np.asarray(a) for a in init[:3])
-            h = max(((np.ptp(x) * np.ptp(y) * np.ptp(z)) / max(1, len(x))) ** (1.0 / 3.0), 1e-30)
-            key = (np.floor((z - z.min()) / h).astype(np.int64) * 100000 + np.floor((y - y.min()) / h).astype(np.int64)) * 100000 \
-                + np.floor((x - x.min()) / h).astype(np.int64)
-            order = np.argsort(key, kind="stable")
+            cr = p.collision_range
+            if kind == "cube":
+                vol, xlo, zlo = p.cube_x * p.cube_y * p.cube_z, 0.0, 0.0
+            else:
+                vol = 2 * np.pi * p.R_oa ** 2 * p.h_oa + np.pi * p.R_g ** 2 * (p.H - 2 * p.h_oa)
+                xlo, zlo = -p.R_oa, 0.0
+            h = max(0.63 * (vol / len(x)) ** (1.0 / 3.0), 2.01 * cr)
+            cx = np.floor((x - (xlo - h)) / h).astype(np.int64)
+            cy = np.floor((y - (xlo - h)) / h).astype(np.int64)
+            cz = np.floor((z - (zlo - h)) / h).astype(np.int64)
+            order = np.lexsort((cx, cy, cz))
             init = tuple(np.asarray(a)[order] for a in init)
         eng = Engine(p)
         eng.set_stream(stream_ptr)
