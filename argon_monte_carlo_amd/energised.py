@@ -34,7 +34,9 @@ class DirectionSampler:
         phi = self.py_rng.uniform(0, pi)                                     # Temp:121
         theta = acos(costheta)
         Fx = r * cos(phi) * sin(theta)
-        Fy = r * sin(phi) * sin(theta) * self.np_rng.choice([-1, 1])         # Temp:124
+        # Temp:124 is np.random.choice([-1, 1]): for a two-element list the legacy generator draws randint(0, 2) — same
+        # value, same stream consumption (tests/test_host.py checks the equivalence), a quarter of the call overhead
+        Fy = r * sin(phi) * sin(theta) * (-1, 1)[self.np_rng.randint(0, 2)]
         Fz = r * cos(theta)
         return Fx, Fy, Fz
 

@@ -86,3 +86,14 @@ def test_histogram_files_byte_identical_to_the_reference(golden_dir, tmp_path):
     for _, fx, fy in OUT.HIST_FILES:
         for fn in (fx, fy):
             assert open(tmp_path / fn, "rb").read() == bytes(G["file_" + fn]), fn
+
+
+def test_direction_sampler_sign_draw_equals_numpy_choice():
+    """energised.DirectionSampler replaces np.random.choice([-1, 1]) (Temp:124) by randint(0, 2): same values, same
+    position of the legacy Mersenne Twister stream afterwards."""
+    a, b = np.random.RandomState(5), np.random.RandomState(5)
+    for i in range(20000):
+        assert a.choice([-1, 1]) == (-1, 1)[b.randint(0, 2)]
+        if i % 7 == 0:
+            assert a.uniform(low=-1.0, high=1.0) == b.uniform(low=-1.0, high=1.0)
+    assert a.get_state()[2] == b.get_state()[2] and np.array_equal(a.get_state()[1], b.get_state()[1])
