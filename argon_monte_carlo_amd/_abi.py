@@ -73,6 +73,14 @@ class AmcDeviceView(C.Structure):
                 ("xchg_capacity", C.c_int64), ("n", C.c_int64), ("lo", C.c_int64), ("hi", C.c_int64)]
 
 
+class AmcTempRng(C.Structure):
+    """amc_temp_rng (include/argonmc.h): configuration of the opt-in device-side energised-wall sampling."""
+    _fields_ = [("struct_size", C.c_int32), ("n_gl", C.c_int32), ("seed", C.c_uint64),
+                ("t_cold", C.c_double), ("t_hot", C.c_double), ("gap_height", C.c_double), ("gap_bottom_height", C.c_double),
+                ("t_debye_alumina", C.c_double), ("n_alumina", C.c_double), ("boltzman", C.c_double),
+                ("gl_x", C.c_double * 32), ("gl_w", C.c_double * 32)]
+
+
 # numpy dtype with the same layout as amc_path_record
 def path_record_dtype():
     import numpy as np

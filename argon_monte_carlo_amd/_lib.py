@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import (AMC_ABI_VERSION, AmcDeviceView, AmcParams, AmcPathRecord, AmcStepStats)
+from ._abi import (AMC_ABI_VERSION, AmcDeviceView, AmcParams, AmcPathRecord, AmcStepStats, AmcTempRng)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libargonmc.so")
@@ -42,6 +42,9 @@ SIGNATURES = {
                                                                                        C.POINTER(C.c_size_t), _i64p]),
     "amc_temp_begin": (C.c_int, [_ctx, C.c_double]),
     "amc_temp_end": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
+    "amc_temp_cases_device": (C.c_int, [_ctx, C.POINTER(AmcTempRng)]),
+    "amc_temp_device_results": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_temp_device_draws": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),
     "amc_drain_paths": (C.c_int, [_ctx, C.POINTER(AmcPathRecord), C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -163,7 +163,7 @@ void amc_destroy(amc_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
-                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->scan_tmp, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
+                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
                     c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
                     c->W.edge_b, c->W.hist_slot, c->W.hist_x, c->W.hist_y, c->W.hist_z, c->W.ov_head, c->W.ov_next,
@@ -177,6 +177,8 @@ void amc_destroy(amc_ctx *c)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
     if (c->h_pin) hipHostFree(c->h_pin);
+    { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
+      for (void *q : td) if (q) hipFree(q); }
     if (c->pos_send) hipFree(c->pos_send);
     if (c->pos_recv) hipFree(c->pos_recv);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -217,7 +219,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
-    c->d_lay = nullptr; c->scan_tmp = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
+    c->d_lay = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
     c->mg_count_pp = true;
     c->lazy_pending = false;
@@ -225,6 +227,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->mg_ncand = 0;
     c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0;
     c->pos_send = c->pos_recv = nullptr; c->pos_world = 0; c->pos_m = 0;
+    c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
+    c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
     c->stream = nullptr;
     int rc = AMC_OK;
 #define CK(call)                                                                                       \
@@ -258,7 +262,6 @@ int amc_create(amc_ctx **out, const amc_params *p)
             CK(dalloc(&c->B.head, nc + 1));
             CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
             c->B.epoch = 0;
-            c->scan_blocks = 0;
             CK(dalloc(&c->W.ov_head, nc));
             CK(hipMemsetAsync(c->W.ov_head, 0xff, sizeof(int) * std::max<size_t>(nc, 1), c->stream));
         }
@@ -733,7 +736,6 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
     return AMC_OK;
 }
 
-// ---- not yet available in this build ----------------------------------------------------------------------------------
 // ---- energised walls (Temp) ---------------------------------------------------------------------------------------------
 static int temp_ensure(amc_ctx *c)
 {
@@ -828,6 +830,129 @@ int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double 
     return AMC_OK;
 }
 
+// ---- device-RNG mode ---------------------------------------------------------------------------------------------------------
+static int temp_dev_ensure(amc_ctx *c)
+{
+    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "energised-wall calls need AMC_GEOM_PORE_ENERGISED");
+    amc_temp_dev_ws &D = c->TD;
+    if (D.idx) return AMC_OK;
+    D.cap = (int)std::min<int64_t>(std::max<int64_t>(4096, c->n / 64 + 1024), 0x0fffffff);
+    const size_t cap = (size_t)D.cap * 7;
+    AMC_HIP(c, dalloc(&D.idx, cap)); AMC_HIP(c, dalloc(&D.count, 8)); AMC_HIP(c, dalloc(&D.t, cap));
+    AMC_HIP(c, dalloc(&D.contact, 3 * cap)); AMC_HIP(c, dalloc(&D.normal, 3 * cap)); AMC_HIP(c, dalloc(&D.dir, 3 * cap));
+    AMC_HIP(c, dalloc(&D.Es, cap)); AMC_HIP(c, dalloc(&D.dpz, cap)); AMC_HIP(c, dalloc(&D.dE, cap)); AMC_HIP(c, dalloc(&D.ok, cap));
+    return AMC_OK;
+}
+
+int amc_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(amc_temp_rng) || cfg->n_gl < 2 || cfg->n_gl > 32)
+        return amc_fail(c, AMC_ERR_INVALID, "amc_temp_rng: bad struct_size / n_gl");
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_dev_ensure(c);
+    if (rc) return rc;
+    if (!c->keep_prior) return amc_fail(c, AMC_ERR_STATE, "amc_temp_cases_device follows amc_temp_begin");
+    c->TD.fetched = false;
+    AMC_HIP(c, amc_launch_temp_cases_device(c, cfg));
+    return AMC_OK;
+}
+
+// counts of all seven cases and the head of every segment in one synchronisation; longer segments are completed here
+static int temp_dev_fetch(amc_ctx *c)
+{
+    amc_temp_dev_ws &D = c->TD;
+    if (D.fetched) return AMC_OK;
+    const int pre = std::min(D.cap, 2048);
+    {
+        amc_stage st(c);
+        AMC_HIP(c, st.get(D.h_count, D.count, sizeof(int) * 7));
+        for (int s = 0; s < 7; s++) {
+            const size_t o = (size_t)s * (size_t)D.cap;
+            D.h_idx[s].resize((size_t)pre); D.h_dpz[s].resize((size_t)pre); D.h_dE[s].resize((size_t)pre); D.h_ok[s].resize((size_t)pre);
+            AMC_HIP(c, st.get(D.h_idx[s].data(), D.idx + o, sizeof(int) * (size_t)pre));
+            AMC_HIP(c, st.get(D.h_dpz[s].data(), D.dpz + o, sizeof(double) * (size_t)pre));
+            AMC_HIP(c, st.get(D.h_dE[s].data(), D.dE + o, sizeof(double) * (size_t)pre));
+            AMC_HIP(c, st.get(D.h_ok[s].data(), D.ok + o, (size_t)pre));
+        }
+        AMC_HIP(c, st.finish());
+    }
+    for (int s = 0; s < 7; s++) {
+        if (D.h_count[s] > D.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits in case %d exceed the record capacity %d", D.h_count[s], 3 + s, D.cap);
+        const size_t k = (size_t)std::max(D.h_count[s], 0);
+        if ((int)k > pre) {
+            const size_t o = (size_t)s * (size_t)D.cap;
+            D.h_idx[s].resize(k); D.h_dpz[s].resize(k); D.h_dE[s].resize(k); D.h_ok[s].resize(k);
+            amc_stage st(c);
+            AMC_HIP(c, st.get(D.h_idx[s].data(), D.idx + o, sizeof(int) * k));
+            AMC_HIP(c, st.get(D.h_dpz[s].data(), D.dpz + o, sizeof(double) * k));
+            AMC_HIP(c, st.get(D.h_dE[s].data(), D.dE + o, sizeof(double) * k));
+            AMC_HIP(c, st.get(D.h_ok[s].data(), D.ok + o, k));
+            AMC_HIP(c, st.finish());
+        }
+    }
+    D.fetched = true;
+    return AMC_OK;
+}
+
+int amc_temp_device_results(amc_ctx *c, int case_id, int32_t *idx, double *dpz, double *dE, uint8_t *ok, size_t cap, size_t *n)
+{
+    if (!c || !n || case_id < 3 || case_id > 9 || !c->TD.idx) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_dev_fetch(c);
+    if (rc) return rc;
+    amc_temp_dev_ws &D = c->TD;
+    const int s = case_id - 3;
+    const size_t k = (size_t)std::max(D.h_count[s], 0);
+    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%zu wall hits, caller buffer holds %zu", k, cap);
+    std::vector<int> perm(k);
+    for (size_t u = 0; u < k; u++) perm[u] = (int)u;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });   // ascending particle index
+    for (size_t u = 0; u < k; u++) {
+        const int r = perm[u];
+        if (idx) idx[u] = D.h_idx[s][r];
+        if (dpz) dpz[u] = D.h_dpz[s][r];
+        if (dE) dE[u] = D.h_dE[s][r];
+        if (ok) ok[u] = D.h_ok[s][r];
+    }
+    *n = k;
+    return AMC_OK;
+}
+
+int amc_temp_device_draws(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
+                          double *surface_energy, size_t cap, size_t *n)
+{
+    if (!c || !n || case_id < 3 || case_id > 9 || !c->TD.idx) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_dev_fetch(c);
+    if (rc) return rc;
+    amc_temp_dev_ws &D = c->TD;
+    const int s = case_id - 3;
+    const size_t k = (size_t)std::max(D.h_count[s], 0), o = (size_t)s * (size_t)D.cap;
+    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%zu wall hits, caller buffer holds %zu", k, cap);
+    *n = k;
+    if (!k) return AMC_OK;
+    std::vector<double> hn(3 * k), hc(3 * k), hd(3 * k), he(k);
+    AMC_HIP(c, hipMemcpy(hn.data(), D.normal + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
+    AMC_HIP(c, hipMemcpy(hc.data(), D.contact + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
+    AMC_HIP(c, hipMemcpy(hd.data(), D.dir + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
+    AMC_HIP(c, hipMemcpy(he.data(), D.Es + o, sizeof(double) * k, hipMemcpyDeviceToHost));
+    std::vector<int> perm(k);
+    for (size_t u = 0; u < k; u++) perm[u] = (int)u;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });
+    for (size_t u = 0; u < k; u++) {
+        const int r = perm[u];
+        if (idx) idx[u] = D.h_idx[s][r];
+        for (int e = 0; e < 3; e++) {
+            if (normal_xyz) normal_xyz[3 * u + e] = hn[3 * r + e];
+            if (dir_xyz) dir_xyz[3 * u + e] = hd[3 * r + e];
+        }
+        if (contact_z) contact_z[u] = hc[3 * r + 2];
+        if (surface_energy) surface_energy[u] = he[r];
+    }
+    return AMC_OK;
+}
+
 int amc_temp_end(amc_ctx *c, amc_step_stats *out)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
@@ -887,7 +1012,9 @@ int amc_mg_positions_view(amc_ctx *c, int world, void **send, void **recv, int64
     if (!c || world < 1 || !send || !recv || !m) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->pos_world != world) {
-        if (c->pos_send) hipFree(c->pos_send);
+        { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
+      for (void *q : td) if (q) hipFree(q); }
+    if (c->pos_send) hipFree(c->pos_send);
         if (c->pos_recv) hipFree(c->pos_recv);
         c->pos_send = c->pos_recv = nullptr;
         c->pos_m = (c->n + world - 1) / world;

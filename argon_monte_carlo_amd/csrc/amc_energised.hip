@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, a
                                                     double *__restrict__ dE)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < 0) n = min(*R.count, R.cap);        // device-RNG mode: the host never saw the count
     if (k >= n) return;
     dpz[k] = 0; dE[k] = 0;
     if (!R.ok[k]) { atomicAdd(&O.cnt->n_fp_errors, 1ULL); atomicAdd(&O.cnt->n_wall, 1ULL); return; }
@@ -132,5 +133,98 @@ hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n)
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_temp_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->P, c->out, case_id, n,
                        make_records(c), c->T.dir, c->T.Es, c->T.dpz, c->T.dE);
+    return hipGetLastError();
+}
+
+
+// ---- opt-in non-parity mode: directions and energies drawn on the device (include/argonmc.h, amc_temp_rng) -----------
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a hit's random numbers depend only on (seed, particle, step,
+// case, attempt) — not on the order the hits were found in, the shard layout or the launch geometry.
+__device__ inline void philox_round(unsigned int (&c)[4], const unsigned int (&k)[2])
+{
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k[0], n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k[1], n3 = (unsigned int)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ inline void philox4x32_10(unsigned int (&c)[4], unsigned long long seed)
+{
+    unsigned int k[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+}
+
+// surface_energy_gap (Temp:143-152): 9 T n k (T/theta)^3 * integral_0^{theta/T} x^3/(e^x - 1) dx, Gauss-Legendre
+__device__ inline double temp_gap_energy(const amc_temp_rng &g, double z)
+{
+    const double m = (g.t_cold - g.t_hot) / g.gap_height;                            // Temp:144
+    const double t_gap = m * (z - g.gap_bottom_height) + g.t_hot;                    // Temp:145
+    const double X = g.t_debye_alumina / t_gap, half = 0.5 * X;
+    double q = 0.0;
+    for (int i = 0; i < g.n_gl; i++) {
+        const double x = half * (g.gl_x[i] + 1.0);
+        q += g.gl_w[i] * (x * x * x / expm1(x));
+    }
+    q *= half;
+    const double r = t_gap / g.t_debye_alumina;
+    return 9 * t_gap * g.n_alumina * g.boltzman * (r * r * r) * q;                   // Temp:152
+}
+
+__global__ __launch_bounds__(256) void k_temp_sample(amc_params P, amc_temp_rng g, int case_id, unsigned int step,
+                                                     temp_records R, double *__restrict__ dir, double *__restrict__ Es)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(*R.count, R.cap)) return;
+    dir[3 * k] = dir[3 * k + 1] = dir[3 * k + 2] = 0.0;
+    Es[k] = 0.0;
+    if (!R.ok[k]) return;
+    const double n0 = R.normal[3 * k], n1 = R.normal[3 * k + 1], n2 = R.normal[3 * k + 2];
+    const double cos85 = 0.087155742747658166;      // cos(85 deg), Temp:136
+    const double pi = 3.14159265358979323846;
+    double fx = 0, fy = 0, fz = 0;
+    for (unsigned int attempt = 0; attempt < 4096u; attempt++) {                     // Temp:133-141 (acceptance ~91 %)
+        unsigned int c[4] = {(unsigned int)R.idx[k], step, ((unsigned int)case_id << 16) | attempt, 0x414d4331u};
+        philox4x32_10(c, g.seed);
+        const double u1 = (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
+        const double u2 = (double)((((unsigned long long)c[2] << 32) | c[3]) >> 12) * (1.0 / 4503599627370496.0);
+        const double costheta = -1.0 + 2.0 * u1;                                     // Temp:120  U(-1, 1)
+        const double phi = pi * u2;                                                  // Temp:121  U(0, pi)
+        const double sgn = (c[3] & 1u) ? 1.0 : -1.0;                                 // Temp:124  choice([-1, 1])
+        const double theta = acos(costheta);
+        fx = cos(phi) * sin(theta);
+        fy = sin(phi) * sin(theta) * sgn;
+        fz = cos(theta);
+        const double d = fma(fz, n2, fma(fy, n1, fx * n0));
+        if (fabs(d) < cos85) continue;                                               // Temp:135-136
+        if (d < cos85) { fx = -fx; fy = -fy; fz = -fz; }                             // Temp:138-139
+        break;
+    }
+    dir[3 * k] = fx; dir[3 * k + 1] = fy; dir[3 * k + 2] = fz;
+    Es[k] = (case_id == 5) ? temp_gap_energy(g, R.contact[3 * k + 2])
+                           : ((case_id == 3 || case_id == 7 || case_id == 9) ? P.E_cold : P.E_hot);
+}
+
+hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
+{
+    const long long cnt = c->hi - c->lo;
+    amc_temp_dev_ws &D = c->TD;
+    hipError_t e = hipMemsetAsync(D.count, 0, sizeof(int) * 7, c->stream);
+    if (e != hipSuccess || cnt <= 0) return e;
+    const unsigned rec_blocks = (unsigned)((D.cap + 255) / 256);
+    for (int s = 0; s < 7; s++) {
+        const int case_id = 3 + s;
+        const size_t o = (size_t)s * (size_t)D.cap;
+        temp_records R;
+        R.idx = D.idx + o; R.t = D.t + o; R.contact = D.contact + 3 * o; R.normal = D.normal + 3 * o; R.ok = D.ok + o;
+        R.count = D.count + s; R.cap = D.cap;
+        hipLaunchKernelGGL(k_temp_hits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, case_id,
+                           c->lo, c->hi, R, c->d_cnt);
+        hipLaunchKernelGGL(k_temp_sample, dim3(rec_blocks), dim3(256), 0, c->stream, c->P, *cfg, case_id,
+                           (unsigned int)c->out.step, R, D.dir + 3 * o, D.Es + o);
+        hipLaunchKernelGGL(k_temp_apply, dim3(rec_blocks), dim3(256), 0, c->stream, c->S, c->P, c->out, case_id, -1, R,
+                           D.dir + 3 * o, D.Es + o, D.dpz + o, D.dE + o);
+    }
     return hipGetLastError();
 }

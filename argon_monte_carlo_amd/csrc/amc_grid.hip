@@ -24,7 +24,7 @@
 // stand-alone form (the step driver builds the lists inside k_stream; this one serves the stage API and multi-GPU,
 // where positions arrive through the all-gather)
 __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x, const double *__restrict__ y,
-                                                   const double *__restrict__ z, long long n, amc_grid G, amc_sorted B,
+                                                   const double *__restrict__ z, long long n, amc_grid G, amc_lists B,
                                                    amc_dev_counters *cnt)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -82,7 +82,7 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 // Measured on MI355X (tools/ubench_vmem.hip): random 8..32-byte loads over a >L2 footprint run at ~5.5e10 requests/s
 // whatever their width, index-ordered ones at ~2e11/s — the kernel's cost is its number of random requests
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
-__global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_sorted B, long long n, double cr2i, double cr_probe,
+__global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
                                                       amc_state S, double *cst)
 {

@@ -27,7 +27,7 @@ AMC_DEV int amc_grid_cell(const amc_grid &G, int cx, int cy, int cz, bool *outsi
 }
 
 // The stored cells that can hold a particle within distance r (<= h/2) of (x,y,z), as up to four runs of x-adjacent
-// cells [c_lo, c_hi] (contiguous in the sorted arrays).  One floor per axis: with f = fractional position inside the
+// cells [c_lo, c_hi] (adjacent entries of the head table).  One floor per axis: with f = fractional position inside the
 // cell, the lower neighbour is needed iff f < r/h and the upper one iff f > 1 - r/h; the thresholds are inflated by
 // 1e-6 cells, far above the rounding of (v - v0) * inv_h (~1e-13 cells), so the set is a superset of the exact one
 // under the same monotone clamps that binning applies.  Returns the number of runs.
@@ -62,13 +62,13 @@ AMC_DEV int amc_grid_box_ranges(const amc_grid &G, double x, double y, double z,
 AMC_DEV int amc_rec_next(const double4 &r) { return (int)__double_as_longlong(r.w); }
 AMC_DEV double amc_rec_pack(int next) { return __longlong_as_double((long long)next); }
 // first particle of cell c in the current epoch, or -1
-AMC_DEV int amc_list_head(const amc_sorted &B, int c)
+AMC_DEV int amc_list_head(const amc_lists &B, int c)
 {
     const unsigned long long h = B.head[c];
     return ((unsigned int)(h >> 32) == B.epoch) ? (int)(unsigned int)(h & 0xffffffffULL) : -1;
 }
 // push particle p (position x,y,z) on the list of its cell; writes its record
-AMC_DEV void amc_list_insert(const amc_grid &G, const amc_sorted &B, int p, double x, double y, double z, bool *outside)
+AMC_DEV void amc_list_insert(const amc_grid &G, const amc_lists &B, int p, double x, double y, double z, bool *outside)
 {
     int cx, cy, cz;
     amc_grid_coords(G, x, y, z, cx, cy, cz);

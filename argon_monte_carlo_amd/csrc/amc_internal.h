@@ -33,7 +33,7 @@ struct amc_grid {
 //   head[c] = (epoch << 32) | particle   — a head whose epoch is not the current one means "empty", so nothing is ever
 //                                          re-zeroed and no scan / scatter pass is needed;
 //   rec[p]  = (x, y, z, next-particle-as-bits) — 32 bytes, written coalesced (indexed by the particle itself).
-struct amc_sorted {
+struct amc_lists {
     unsigned long long *head; // [ncells]
     double4 *rec;             // [n]
     unsigned int epoch;       // current binning epoch (>= 1)
@@ -90,6 +90,19 @@ struct amc_temp_ws {
     std::vector<int> perm;       // sorted position -> record slot of the pending hits
 };
 
+// device-RNG mode (amc_temp_cases_device): one record segment per energised case, kept until the next step
+struct amc_temp_dev_ws {
+    int *idx, *count;            // [7 * cap], [7]
+    double *t, *contact, *normal, *dir, *Es, *dpz, *dE;
+    unsigned char *ok;
+    int cap;                     // records per case
+    bool fetched;                // host copies below are valid for the last step
+    int h_count[7];
+    std::vector<int> h_idx[7];
+    std::vector<double> h_dpz[7], h_dE[7];
+    std::vector<unsigned char> h_ok[7];
+};
+
 struct amc_ctx {
     amc_params P;
     int device;
@@ -102,11 +115,10 @@ struct amc_ctx {
     amc_grid G;
     std::vector<int> h_lay_lo, h_lay_n, h_lay_off;
     int *d_lay;               // device copy of the three layer tables, contiguous
-    amc_sorted B;
-    int *scan_tmp;            // (unused since the counting sort was replaced by per-cell lists)
-    int scan_blocks;
+    amc_lists B;
     amc_resolve_ws W;
     amc_temp_ws T;
+    amc_temp_dev_ws TD;
     bool allpairs;
     // outputs
     amc_out out;
@@ -168,6 +180,7 @@ hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
 hipError_t amc_launch_commit(amc_ctx *c);
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
+hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg);
 hipError_t amc_launch_pos_pack(amc_ctx *c, int world, int rank, int unpack);
 hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack);
 // the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)

@@ -37,7 +37,7 @@ struct rs_args {
     amc_params P;
     amc_state S;
     amc_grid G;
-    amc_sorted B;
+    amc_lists B;
     amc_resolve_ws W;
     amc_out O;
     long long n;
@@ -424,8 +424,8 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const int pme = W.sl_p[sme];
     const int lme = label[sme];
     const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
-    // only the cells overlapped by the collision_range box around the new position can hold a partner (1.7 cells on
-    // average): fetch their bounds and overlay heads first, then the entries in batches
+    // only the cells overlapped by the collision_range box around the new position can hold a partner (2 to 3 on
+    // average): fetch their list heads and overlay heads first, then the entries
     int c_lo[4], c_hi[4], lh[8], ovh[8];
     const int ncell = amc_grid_box_ranges(G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
     // list heads and overlay heads of every overlapped cell first (one memory round trip), then the entries

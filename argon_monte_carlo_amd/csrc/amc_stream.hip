@@ -15,7 +15,7 @@
 template <int GEOM>
 __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
                                                 long long lo, long long hi, int keep_prior, int bounds_slot,
-                                                amc_grid G, amc_sorted B, int build_lists, amc_lazy L)
+                                                amc_grid G, amc_lists B, int build_lists, amc_lazy L)
 {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;

@@ -131,3 +131,43 @@ def drive_energised_cases(hooks, sampler, energies):
             hot = hot + sequential_sum(dE[k] for k in good)
             had_h = had_h or len(good) > 0
     return mom, cold, hot, had_m, had_c, had_h
+
+
+def device_rng_config(consts, seed, n_gl=32):
+    """amc_temp_rng for the opt-in, NON-PARITY device-side sampling (include/argonmc.h): Philox seed, the constants of
+    surface_energy_gap (Temp:143-152) and a Gauss-Legendre rule for its Debye integral."""
+    from ._abi import AmcTempRng
+    import ctypes as C
+    x, w = np.polynomial.legendre.leggauss(int(n_gl))
+    g = AmcTempRng()
+    g.struct_size, g.n_gl, g.seed = C.sizeof(AmcTempRng), int(n_gl), int(seed) & 0xFFFFFFFFFFFFFFFF
+    g.t_cold, g.t_hot = consts["t_cold"], consts["t_hot"]
+    g.gap_height = consts["gap_height"]
+    g.gap_bottom_height = consts["open_air_height"] + consts["hot_coating_height"]          # Temp:45
+    g.t_debye_alumina, g.n_alumina = consts["t_debye_alumina"], consts["num_atoms_unitcell_alumina"]
+    g.boltzman = consts["boltzman"]
+    for i in range(int(n_gl)):
+        g.gl_x[i], g.gl_w[i] = float(x[i]), float(w[i])
+    return g
+
+
+def sum_device_cases(results):
+    """Per-step sums from the per-hit results of the seven cases, accumulated like drive_energised_cases does
+    (left-to-right in ascending particle index within a case, cases in Temp:708-751 order).  ``results[case]`` =
+    (dpz, dE, ok)."""
+    mom = cold = hot = 0
+    had_m = had_c = had_h = False
+    for case in CASES:
+        dpz, dE, ok = results[case]
+        good = [k for k in range(len(ok)) if ok[k]]
+        if len(ok) == 0:
+            continue
+        mom = mom + sequential_sum(dpz[k] for k in good)
+        had_m = had_m or len(good) > 0
+        if case in COLD_CASES:
+            cold = cold + sequential_sum(dE[k] for k in good)
+            had_c = had_c or len(good) > 0
+        elif case in HOT_CASES:
+            hot = hot + sequential_sum(dE[k] for k in good)
+            had_h = had_h or len(good) > 0
+    return mom, cold, hot, had_m, had_c, had_h

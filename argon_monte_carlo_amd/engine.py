@@ -290,6 +290,41 @@ class EnergisedEngine(Engine):
         self._ck(self.lib.amc_temp_end(self._ctx, C.byref(st)))
         return st.as_dict()
 
+    # ---- opt-in, non-parity: directions / energies drawn on the device (no host hand-over) ---------------------------
+    def temp_cases_device(self, cfg):
+        self._ck(self.lib.amc_temp_cases_device(self._ctx, C.byref(cfg)))
+
+    def device_results(self, case):
+        cap = max(4096, self.n // 64 + 1024)
+        idx = np.empty(cap, dtype=np.int32)
+        dpz, dE = np.empty(cap), np.empty(cap)
+        ok = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._ck(self.lib.amc_temp_device_results(self._ctx, int(case), idx.ctypes.data_as(C.POINTER(C.c_int32)), _d(dpz), _d(dE),
+                                                  ok.ctypes.data_as(C.POINTER(C.c_uint8)), cap, C.byref(n)))
+        k = n.value
+        return idx[:k].copy(), dpz[:k].copy(), dE[:k].copy(), ok[:k].astype(bool)
+
+    def device_draws(self, case):
+        cap = max(4096, self.n // 64 + 1024)
+        idx = np.empty(cap, dtype=np.int32)
+        normal, dirs = np.empty((cap, 3)), np.empty((cap, 3))
+        cz, Es = np.empty(cap), np.empty(cap)
+        n = C.c_size_t(0)
+        self._ck(self.lib.amc_temp_device_draws(self._ctx, int(case), idx.ctypes.data_as(C.POINTER(C.c_int32)), _d(normal), _d(cz),
+                                                _d(dirs), _d(Es), cap, C.byref(n)))
+        k = n.value
+        return idx[:k].copy(), normal[:k].copy(), cz[:k].copy(), dirs[:k].copy(), Es[:k].copy()
+
+    def temp_timestep_device(self, dt, cfg):
+        """temp_timestep with the random draws on the device: same return tuple, no per-case host round trip."""
+        from .energised import CASES, sum_device_cases
+        self.temp_begin(dt)
+        self.temp_cases_device(cfg)
+        st = self.temp_end()
+        res = {case: self.device_results(case)[1:] for case in CASES}
+        return (st,) + sum_device_cases(res)
+
     def temp_timestep(self, dt, sampler, energies):
         """One iteration of Temperature_Pore_MC.py's loop (Temp:662-853)."""
         from .energised import drive_energised_cases

@@ -169,7 +169,11 @@ class TemperatureSimulation(Simulation):
     (Temp:634-638, 756-758, 929-933).  The random directions come from ``np.random`` / ``random`` (module-level streams
     by default, as in the reference) in strict particle order; see energised.py."""
 
-    def __init__(self, n=None, sigma=PR.SIGMA, device=0, np_rng=None, py_rng=None, params=None, consts=None):
+    def __init__(self, n=None, sigma=PR.SIGMA, device=0, np_rng=None, py_rng=None, params=None, consts=None,
+                 device_rng_seed=None):
+        """``device_rng_seed``: opt-in, NON-PARITY mode — re-emission directions and gap energies are drawn on the GPU
+        (Philox4x32-10 keyed by the seed, Gauss-Legendre Debye integral) instead of from ``np.random`` / ``random`` /
+        ``mpmath``; same physics and recipe, different random numbers, no per-case host hand-over."""
         from .energised import DirectionSampler, SurfaceEnergies
         from .engine import EnergisedEngine
         if params is None:
@@ -182,6 +186,10 @@ class TemperatureSimulation(Simulation):
         params.E_cold, params.E_hot = self.energies.cold, self.energies.hot
         self.engine = EnergisedEngine(params)
         self.sampler = DirectionSampler(np_rng, py_rng)
+        self._device_rng = None
+        if device_rng_seed is not None:
+            from .energised import device_rng_config
+            self._device_rng = device_rng_config(consts, device_rng_seed)
         self.completed_paths, self.completed_x_paths = [], []
         self.completed_y_paths, self.completed_z_paths = [], []
         self.num_collisions_per_step = 0
@@ -198,8 +206,12 @@ class TemperatureSimulation(Simulation):
         self.set_state(*IC.pore_ic(self.params, self.consts, seed if seed is not None else self.consts["seed"]))
 
     def timestep(self, dt=None, collect_paths=True):
-        st, mom, cold, hot, had_m, had_c, had_h = self.engine.temp_timestep(self.dt if dt is None else dt, self.sampler,
-                                                                            self.energies)
+        if self._device_rng is not None:
+            st, mom, cold, hot, had_m, had_c, had_h = self.engine.temp_timestep_device(self.dt if dt is None else dt,
+                                                                                       self._device_rng)
+        else:
+            st, mom, cold, hot, had_m, had_c, had_h = self.engine.temp_timestep(self.dt if dt is None else dt,
+                                                                                self.sampler, self.energies)
         self._cache = None
         self.momentum_z_change_per_step.append(mom)
         self.energy_transfer_cold_per_step.append(cold)

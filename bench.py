@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
     ap.add_argument("--sorted-ic", action="store_true", help="experiment: upload the particles in spatial (cell) order")
+    ap.add_argument("--device-rng", action="store_true",
+                    help="temp workloads: opt-in NON-PARITY mode, re-emission directions / gap energies drawn on the GPU (Philox)")
     ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
     args = ap.parse_args()
     # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner at communicator
@@ -163,6 +165,7 @@ def main():
         n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
         p.reserved0 |= 1
+        p.E_cold, p.E_hot = SurfaceEnergies(c).cold, SurfaceEnergies(c).hot          # Temp:83-84
         if sharded:
             from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
             eng = ShardedTemperatureSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
@@ -173,14 +176,24 @@ def main():
         sampler = DirectionSampler(np.random.RandomState(17), random.Random(17))     # same streams on every rank
         energies = SurfaceEnergies(c)
 
+        p_dev = None
+        if args.device_rng:
+            if sharded:
+                raise SystemExit("--device-rng is a single-GPU option")
+            from argon_monte_carlo_amd.energised import device_rng_config
+            p_dev = device_rng_config(c, 17)
+
         def step(k):
             tot = None
             for _ in range(k):
-                st = eng.temp_timestep(c["dt"], sampler, energies)[0]
+                st = (eng.temp_timestep_device(c["dt"], p_dev) if p_dev is not None else
+                      eng.temp_timestep(c["dt"], sampler, energies))[0]
                 tot = st if tot is None else {kk: tot[kk] + st[kk] for kk in st}
             return tot
         parallelism = ("single GPU" if not sharded else f"index-range shards x{world}, hits concatenated in index order, "
-                       "per-step all-gather of positions (RCCL)") + " + host RNG/mpmath hand-over per energised case"
+                       "per-step all-gather of positions (RCCL)") + \
+            (" + device-side Philox sampling (opt-in, NOT the reference's random streams)" if args.device_rng else
+             " + host RNG/mpmath hand-over per energised case")
         engines = [eng.engine if sharded else eng]
     elif world == 1 and not args.force_sharded:
         p, c, init = make_workload(args.workload, n_per_gpu, device=local_rank)

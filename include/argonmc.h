@@ -220,6 +220,29 @@ int amc_paths_pending(amc_ctx *ctx, size_t *n);
 int amc_histograms(amc_ctx *ctx, uint64_t *counts, uint64_t *n_paths_total);
 int amc_reset_outputs(amc_ctx *ctx);
 
+/* ---- opt-in, NON-PARITY mode: the energised cases entirely on the device ----------------------------------
+ * The reference draws the re-emission direction of every hit from two Mersenne Twisters in particle order with a
+ * rejection loop (Temp:119-141) and integrates the gap wall's surface energy with mpmath (Temp:143-152); reproducing
+ * its numbers needs the host hand-over above.  This mode keeps the recipe and replaces the generators: a counter-based
+ * Philox4x32-10 keyed by `seed`, counter = (particle, step, case, attempt) — results do not depend on hit order, shard
+ * layout or launch geometry — and a Gauss-Legendre rule for the Debye integral.  Everything else (masks, contact
+ * points, accommodation, bookkeeping) is the same code as the parity path.
+ *   amc_temp_begin(dt) -> amc_temp_cases_device(cfg) -> amc_temp_end(&stats), no host synchronisation in between;
+ *   amc_temp_device_results(case, ...) afterwards returns the per-hit z-momentum / energy changes of that case in
+ *   ascending particle index (the order Temp:385-389 sums them in); amc_temp_device_draws is for inspection / tests. */
+typedef struct amc_temp_rng {
+    int32_t struct_size;          /* sizeof(amc_temp_rng)                                                        */
+    int32_t n_gl;                 /* Gauss-Legendre points in use, 2..32                                         */
+    uint64_t seed;
+    double t_cold, t_hot, gap_height, gap_bottom_height;      /* Temp:31-32, 44-45, 144-145                      */
+    double t_debye_alumina, n_alumina, boltzman;              /* Temp:148-152                                    */
+    double gl_x[32], gl_w[32];    /* nodes and weights on [-1, 1]                                                */
+} amc_temp_rng;
+int amc_temp_cases_device(amc_ctx *ctx, const amc_temp_rng *cfg);
+int amc_temp_device_results(amc_ctx *ctx, int case_id, int32_t *idx, double *dpz, double *dE, uint8_t *ok, size_t cap, size_t *n);
+int amc_temp_device_draws(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
+                          double *surface_energy, size_t cap, size_t *n);
+
 /* ---- multi-GPU (one process per GPU; particles sharded by index range) ------------------------------
  * Every rank allocates all n particles but advances only its shard [lo, hi).  Per step (argon_monte_carlo_amd/dist.py):
  *   amc_mg_local            drift + walls + bounds on [lo,hi)                       (Pore:426-512 on the shard)
@@ -271,8 +294,8 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 /* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
 #define AMC_K_DRIFT_WALLS 0
 #define AMC_K_BIN_COUNT 1        /* k_bin_lists: stand-alone build of the per-cell lists (the step driver fuses it into k_stream) */
-#define AMC_K_BIN_SCAN 2         /* unused */
-#define AMC_K_BIN_SCATTER 3      /* unused */
+#define AMC_K_BIN_SCAN 2         /* reserved (no such pass: the lists need neither scan nor scatter) */
+#define AMC_K_BIN_SCATTER 3      /* reserved */
 #define AMC_K_DETECT 4
 #define AMC_K_RESOLVE 5          /* k_resolve, first launch of a sweep (claim, clusters, emulation; small sweeps: everything) */
 #define AMC_K_BOUNDS 6

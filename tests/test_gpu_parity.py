@@ -561,3 +561,79 @@ def test_checkpoint_resume_continues_bit_identically(golden_dir, tmp_path):
             assert any(float(v) != 0.0 for v in ref.momentum_z_change_per_step)
         b.close()
         ref.close()
+
+
+# ---------------------------------------------------------------------------------------------- opt-in device-side energised sampling
+def test_device_rng_energised_walls_match_oracle_on_the_same_draws(O):
+    """SURVEY 8f-4 (non-parity mode): with directions / energies drawn on the GPU, everything ELSE must still be the
+    reference's arithmetic — the oracle replays each case with the draws the device used and has to land on the same
+    state bit for bit; the draws themselves are checked against the Philox reference (pinned to the published
+    known-answer vectors), the re-emission recipe (Temp:119-141) and the mpmath gap energy (Temp:143-152)."""
+    import math
+    from argon_monte_carlo_amd.energised import CASES, GAP_CASE, SurfaceEnergies, device_rng_config
+    from argon_monte_carlo_amd.engine import EnergisedEngine
+    from tests.philox_ref import direction_draw
+    p, c = PR.pore_params(n=1_000_000, energised=True)
+    p.reserved0 |= 1
+    init = IC.pore_ic(p, c, seed=29)
+    seed = 0x1234ABCD5678
+    cfg = device_rng_config(c, seed)
+    energies = SurfaceEnergies(c)
+    p.E_cold, p.E_hot = energies.cold, energies.hot          # Temp:83-84 (the constants the device uses for the coated walls)
+    eng = EnergisedEngine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(*init)
+    orc.upload(*init)
+    dt = c["dt"]
+    cos85 = math.cos(85 * math.pi / 180)
+    n_hits = n_gap = 0
+    for s in range(3):
+        st, mom, cold, hot, hm, hc, hh = eng.temp_timestep_device(dt, cfg)
+        orc._temp_wall_count = 0
+        orc._temp_errs = 0
+        orc.drift(dt, True)
+        orc.temp_specular()
+        omom = 0.0
+        for case in CASES:
+            idx, nm, cz, ok = orc.wall_hits(case)
+            didx, dn, dcz, ddir, dEs = eng.device_draws(case)
+            assert np.array_equal(idx, didx), (s, case)
+            assert np.array_equal(nm, dn) and np.array_equal(cz, dcz), (s, case)
+            dpz, dE = orc.wall_apply(case, ddir, dEs)
+            ridx, rdpz, rdE, rok = eng.device_results(case)
+            assert np.array_equal(ridx, idx) and np.array_equal(rok, ok)
+            assert np.array_equal(rdpz, dpz) and np.array_equal(rdE, dE), (s, case)
+            for k in range(len(idx)):
+                if not ok[k]:
+                    continue
+                n_hits += 1
+                omom = omom + float(dpz[k])
+                d = ddir[k]
+                assert abs(np.dot(d, d) - 1.0) < 1e-14
+                assert np.dot(d, nm[k]) >= cos85 * (1 - 1e-12)                      # inbound, outside the grazing band
+                if k < 40:                                                           # the generator itself: first accepted attempt
+                    for attempt in range(64):
+                        ct, phi, sg = direction_draw(seed, int(idx[k]), s, case, attempt)
+                        th = math.acos(ct)
+                        f = np.array([math.cos(phi) * math.sin(th), math.sin(phi) * math.sin(th) * sg, math.cos(th)])
+                        dot = float(np.dot(f, nm[k]))
+                        if abs(dot) < cos85:
+                            continue
+                        if dot < cos85:
+                            f = -f
+                        break
+                    np.testing.assert_allclose(d, f, rtol=0, atol=1e-13)
+                if case == GAP_CASE:
+                    n_gap += 1
+                    assert abs(dEs[k] / energies.gap(cz[k]) - 1.0) < 1e-12
+                else:
+                    assert dEs[k] == (energies.cold if case in (3, 7, 9) else energies.hot)
+        orc.bounds(True)
+        rc, npp, _ = orc.sweep()
+        orc.bounds(True)
+        orc.step += 1
+        assert rc == 0 and st["n_pp"] == npp and st["n_wall"] == orc._temp_wall_count
+        assert_state_equal(eng.download(), orc.state(), ("device rng", s))
+        assert hm and float(mom) != 0.0
+    assert n_hits > 500 and n_gap >= 3
+    eng.close()

@@ -97,3 +97,12 @@ def test_direction_sampler_sign_draw_equals_numpy_choice():
         if i % 7 == 0:
             assert a.uniform(low=-1.0, high=1.0) == b.uniform(low=-1.0, high=1.0)
     assert a.get_state()[2] == b.get_state()[2] and np.array_equal(a.get_state()[1], b.get_state()[1])
+
+
+def test_philox_reference_known_answers():
+    """tests/philox_ref.py against the known-answer vectors of the Random123 distribution (kat_vectors, philox4x32 10)."""
+    from tests.philox_ref import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
