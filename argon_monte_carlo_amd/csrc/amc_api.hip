@@ -170,7 +170,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
                     c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
-                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
+                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
                     c->W.ev_gen, c->W.ev_slot, c->W.hist_gen};
     for (void *p : ptrs)
@@ -289,7 +289,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms)); CK(dalloc(&W.sl_dirty, ms));
         CK(dalloc(&W.sl_gen, ms)); CK(dalloc(&W.sl_hits, ms));
         for (int k = 0; k < 10; k++) CK(dalloc(&W.cw_d[k], ms));
-        CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
+        CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_slot, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
         CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
         CK(dalloc(&W.hist_slot, (size_t)W.max_hist)); CK(dalloc(&W.hist_x, (size_t)W.max_hist));
         CK(dalloc(&W.hist_y, (size_t)W.max_hist)); CK(dalloc(&W.hist_z, (size_t)W.max_hist));
@@ -725,7 +725,7 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
         long long h[16];
         hipMemcpy(h, c->d_dbg, sizeof h, hipMemcpyDeviceToHost);
         const double n = h[11] > 0 ? (double)h[11] : 1.0;
-        fprintf(stderr, "[amc resolve phases, us/launch] claim %.1f label %.1f [collect %.1f tid0-pair %.1f (load %.1f ks %.1f collide+emit %.1f)] pairs-barrier %.1f complex %.1f validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
+        fprintf(stderr, "[amc resolve phases, us/launch] claim %.1f label %.1f [collect %.1f tid0-pair %.1f (load %.1f ks %.1f collide+emit %.1f)] clusters>=3: sort+load %.1f emulate %.1f | validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
                 h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[13] / n / 100.0, h[14] / n / 100.0, h[12] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
                 h[8] / n, h[9] / n, h[10] / n, h[11]);
     }

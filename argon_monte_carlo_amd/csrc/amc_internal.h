@@ -63,7 +63,7 @@ struct amc_resolve_ws {
     int *sl_gen, *sl_hits;    // round in which the slot's cluster was last emulated; collisions counted on the slot
     int *ev_gen, *ev_slot, *hist_gen;   // round tags: results of a re-emulated cluster are superseded, not erased
     double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
-    int *cw_tmp, *cw_pidx;
+    int *cw_tmp, *cw_pidx, *cw_slot;
     uint8_t *cw_flag, *cw_moved;
     int *edge_a, *edge_b;     // extra merge edges (slots) found by verification
     int max_edges;

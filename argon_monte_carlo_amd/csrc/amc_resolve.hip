@@ -67,7 +67,7 @@ struct rs_shared {
 // working set of the multi-particle clusters (LDS pool or global fallback), indexed by sorted rank
 struct rs_work {
     double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
-    int *tmp, *pidx;
+    int *tmp, *pidx, *slot;     // scratch, particle index, slot index of each member
     uint8_t *flag, *moved;
 };
 
@@ -121,7 +121,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
         atomicAdd(&sh->nfp, 1);     // the reference would raise FloatingPointError here (Pore:11,185)
         return false;
     }
-    W.sl_hits[si] += 1;         // only the thread that emulates this cluster touches its slots
+    atomicAdd(&W.sl_hits[si], 1);   // (no value needed back: the thread does not wait for the memory round trip)
     const int h = atomicAdd(&sh->nhist, 2);
     if (h + 1 < W.max_hist) {
         W.hist_gen[h] = sh->cur_round; W.hist_gen[h + 1] = sh->cur_round;
@@ -285,7 +285,7 @@ AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int
     if (!amc_overlap(K.x[wj], K.y[wj], K.z[wj], K.x[wi], K.y[wi], K.z[wi], A.P.collision_range)) return;
     amc_particle p1 = rs_load_work(K, wj), p2 = rs_load_work(K, wi);
     const int pj = K.pidx[wj], pi = K.pidx[wi];
-    if (rs_hit(A, sh, p1, p2, pj, pi, A.W.slot_of[pj], A.W.slot_of[pi], phase, cell)) {
+    if (rs_hit(A, sh, p1, p2, pj, pi, K.slot[wj], K.slot[wi], phase, cell)) {
         rs_store_work(K, wj, p1);
         rs_store_work(K, wi, p2);
     }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     __shared__ rs_shared sh;
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
     __shared__ double pool_d[10][RS_POOL];
-    __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL];
+    __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL], pool_slot[RS_POOL];
     __shared__ uint8_t pool_flag[RS_POOL], pool_moved[RS_POOL];
     __shared__ int s_label[RS_NS], s_size[RS_NS];
     __shared__ unsigned char s_dirty[RS_NS];
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         rs_work K;
         K.x = pool_d[0]; K.y = pool_d[1]; K.z = pool_d[2]; K.vx = pool_d[3]; K.vy = pool_d[4]; K.vz = pool_d[5];
         K.d = pool_d[6]; K.dx = pool_d[7]; K.dy = pool_d[8]; K.dz = pool_d[9];
-        K.tmp = pool_tmp; K.pidx = pool_pidx; K.flag = pool_flag; K.moved = pool_moved;
+        K.tmp = pool_tmp; K.pidx = pool_pidx; K.slot = pool_slot; K.flag = pool_flag; K.moved = pool_moved;
         if (split && tid < 64) {
             unsigned long long *sorted = lds_keys + RS_SORT_LDS / 2;
             const int w = tid;
@@ -647,9 +647,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 rs_store_work(K, w, q);
                 K.moved[w] = 0;
                 K.pidx[w] = p;
+                K.slot[w] = W.slot_of[p];
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[2] += n__ - t_last; t_last = n__; }
             if (w < nc) {
                 const unsigned lab = (unsigned)(sorted[w] >> 32);
                 if (!(w > 0 && (unsigned)(sorted[w - 1] >> 32) == lab)) {        // cluster head
@@ -660,7 +662,8 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            if (w < nc && K.moved[w]) rs_store_slot(W, W.slot_of[K.pidx[w]], rs_load_work(K, w));
+            if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[3] += n__ - t_last; t_last = n__; }
+            if (w < nc && K.moved[w]) rs_store_slot(W, K.slot[w], rs_load_work(K, w));
         } else {
             // ---- two-particle clusters straight from the candidate list, both particles in registers ------------------------
             const int t0 = split ? tid - 64 : tid, tstride = split ? RS_T - 64 : RS_T;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             if (nc > RS_POOL) {
                 K.x = W.cw_d[0]; K.y = W.cw_d[1]; K.z = W.cw_d[2]; K.vx = W.cw_d[3]; K.vy = W.cw_d[4]; K.vz = W.cw_d[5];
                 K.d = W.cw_d[6]; K.dx = W.cw_d[7]; K.dy = W.cw_d[8]; K.dz = W.cw_d[9];
-                K.tmp = W.cw_tmp; K.pidx = W.cw_pidx; K.flag = W.cw_flag; K.moved = W.cw_moved;
+                K.tmp = W.cw_tmp; K.pidx = W.cw_pidx; K.slot = W.cw_slot; K.flag = W.cw_flag; K.moved = W.cw_moved;
             }
             for (int w = tid; w < nc; w += RS_T) {
                 const int p = (int)(keys[w] & 0xffffffffULL);
@@ -696,6 +699,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 rs_store_work(K, w, q);
                 K.moved[w] = 0;
                 K.pidx[w] = p;
+                K.slot[w] = W.slot_of[p];
             }
             __syncthreads();
             for (int w = tid; w < nc; w += RS_T) {
@@ -707,7 +711,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             }
             __syncthreads();
             for (int w = tid; w < nc; w += RS_T)
-                if (K.moved[w]) rs_store_slot(W, W.slot_of[K.pidx[w]], rs_load_work(K, w));
+                if (K.moved[w]) rs_store_slot(W, K.slot[w], rs_load_work(K, w));
         }
         __syncthreads();
         RS_STAMP(3);
@@ -796,8 +800,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
                      W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
         }
-        for (int s2 = tid; s2 < ns; s2 += RS_T)
-            if (W.sl_hits[s2]) atomicAdd(&sh.nhits, W.sl_hits[s2]);
+        for (int s2 = tid; s2 < ns; s2 += RS_T) {
+            // the counts were updated by atomics (performed in L2): read them there too, not from this CU's L1
+            const int hs = __hip_atomic_load(&W.sl_hits[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (hs) atomicAdd(&sh.nhits, hs);
+        }
     }
     __syncthreads();
     RS_STAMP(5);
