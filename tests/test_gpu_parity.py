@@ -637,3 +637,91 @@ def test_device_rng_energised_walls_match_oracle_on_the_same_draws(O):
         assert hm and float(mom) != 0.0
     assert n_hits > 500 and n_gap >= 3
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE config 1 and 2 at full length
+def test_baseline_config1_cube_1000_particles_1000_steps(Engine, O):
+    """BASELINE configs[0]: Open_Air_Cube_MC geometry, 1,000 particles, 1,000 steps — the whole run on the GPU
+    (`amc_run`, both detectors) against the oracle stepping the same run: state bit for bit at every 100th step and at the
+    end, collision totals, and the free-path histograms from the device equal np.histogram of the oracle's path list."""
+    for mode in (1, 2):
+        p, c = PR.cube_params_for_n(1000)
+        p.detect_mode = mode
+        init = IC.cube_ic(p, c, seed=127)
+        eng = Engine(p)
+        orc = O.Oracle(p, mode="mul", path_capacity=1 << 18)
+        eng.upload(*init)
+        orc.upload(*init)
+        tot = dict(n_pp=0, n_paths=0)
+        otot = dict(n_pp=0, n_paths=0)
+        for block in range(10):
+            st = eng.run(c["dt"], 100)
+            for s in range(100):
+                rc, so = orc.timestep(c["dt"])
+                assert rc == 0
+                for k in otot:
+                    otot[k] += so[k]
+            for k in tot:
+                tot[k] += st[k]
+            assert_state_equal(eng.download(), orc.state(), ("config1", mode, block))
+        assert tot == otot and tot["n_pp"] > 1000
+        counts, npaths = eng.histograms()
+        paths = orc.paths()
+        assert npaths == len(paths) == tot["n_paths"]
+        for row, key in enumerate(("total", "px", "py", "pz")):
+            ref, _ = np.histogram(paths[key], bins=p.hist_bins, range=(p.hist_lo, p.hist_hi))
+            assert np.array_equal(counts[row], ref.astype(np.uint64)), (mode, key)
+        eng.close()
+
+
+def test_baseline_config2_cube_1e5_histograms_vs_cpu(Engine, O):
+    """BASELINE configs[1]: cube geometry, N = 100,000 — free-path histograms of a 60-step run (`amc_run`, no host
+    synchronisation inside) equal the CPU oracle's, and so does the final state."""
+    p, c = PR.cube_params_for_n(100_000)
+    init = IC.cube_ic(p, c, seed=127)
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 20)
+    eng.upload(*init)
+    orc.upload(*init)
+    st = eng.run(c["dt"], 60)
+    npp = 0
+    for s in range(60):
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0
+        npp += so["n_pp"]
+    assert st["n_pp"] == npp and npp > 5000
+    assert_state_equal(eng.download(), orc.state(), "config2")
+    counts, npaths = eng.histograms()
+    paths = orc.paths()
+    assert npaths == len(paths) and npaths > 1000
+    for row, key in enumerate(("total", "px", "py", "pz")):
+        ref, _ = np.histogram(paths[key], bins=p.hist_bins, range=(p.hist_lo, p.hist_hi))
+        assert np.array_equal(counts[row], ref.astype(np.uint64)), key
+    eng.close()
+
+
+def test_baseline_config3_pore_5e5_vs_oracle(Engine, O):
+    """BASELINE configs[2]: pore geometry, N = 500,000, specular walls — GPU == oracle bit for bit over several steps
+    (state, every counter), completed-path multiset included."""
+    p, c = PR.pore_params(n=500_000)
+    init = IC.pore_ic(p, c, seed=17)
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(*init)
+    orc.upload(*init)
+    tot = 0
+    for s in range(4):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+            assert st[k] == so[k], (s, k, st, so)
+        tot += st["n_pp"] + st["n_wall"]
+        assert_state_equal(eng.download(), orc.state(), ("config3", s))
+    assert tot > 500
+    rec = eng.drain_paths(sort=True)
+    ref = orc.paths()
+    assert len(rec) == len(ref)
+    for key in ("total", "px", "py", "pz"):
+        assert np.array_equal(np.sort(rec[key]), np.sort(ref[key])), key
+    eng.close()
