@@ -13,6 +13,10 @@
 /* ------------------------------------------------------------------------------------------------------- */
 /* a1 — pairwise_particles_in_cell, Pore:160-255 == Temp:215-309 == Cube:253-324                              */
 /* gidx: global particle index of each member (for the path record keys) or NULL.                            */
+/* amc_params.reserved1 bit0 = "count and continue" (Temp:340-342 semantics applied to every geometry — the library's
+ * option for production runs; the reference's Pore/Cube scripts abort instead): events are tallied here per timestep. */
+static int64_t ORC(fp_tolerated) = 0;
+
 int ORC(pair_cell)(const amc_params *P, int64_t n, double *cont, double *contx, double *conty, double *contz,
                    uint8_t *flag, double *xs, double *ys, double *zs, double *vxs, double *vys, double *vzs,
                    const int32_t *gidx, orc_sink *sink, int32_t step, int32_t phase, int64_t cell,
@@ -34,6 +38,7 @@ int ORC(pair_cell)(const amc_params *P, int64_t n, double *cont, double *contx, 
             double disc2 = SQ(b) - 4 * a * c;
             if (a == 0.0 || disc2 < 0.0 || a != a || disc2 != disc2) {
                 /* np.seterr(all='raise') (Pore:11): divide-by-zero / invalid -> FloatingPointError aborts the run */
+                if (P->reserved1 & 1) { ORC(fp_tolerated)++; continue; }     /* option: skip the pair, keep going */
                 rc = AMC_ERR_FP;
                 goto done;
             }
@@ -112,7 +117,6 @@ int ORC(pore_vertical_wall)(const amc_params *P, orc_state *S, const uint8_t *hi
 int ORC(side_wall)(const amc_params *P, orc_state *S, const uint8_t *hits, double Rc, int bookkeeping, orc_sink *sink,
                    int32_t step, int32_t phase, int64_t *ncoll, int64_t *nerr)
 {
-    (void)P;
     for (int64_t p = 0; p < S->n; p++) {
         if (!hits[p]) continue;
         double x = S->x[p], y = S->y[p], vx = S->vx[p], vy = S->vy[p], vz = S->vz[p];
@@ -123,8 +127,8 @@ int ORC(side_wall)(const amc_params *P, orc_state *S, const uint8_t *hits, doubl
         if (a == 0.0 || disc2 < 0.0 || disc2 != disc2) {
             /* Pore:336-338: the except branch raises UnboundLocalError (total_errs not global) -> run aborts.
              * Temp:340-342: total_errs += 1, particle left untouched. */
-            if (bookkeeping) return AMC_ERR_FP;
-            if (nerr) (*nerr)++;
+            if (bookkeeping && !(P->reserved1 & 1)) return AMC_ERR_FP;
+            if (nerr) (*nerr)++; else ORC(fp_tolerated)++;
             continue;
         }
         double sq = sqrt(disc2);
@@ -535,6 +539,7 @@ int ORC(timestep)(const amc_params *P, orc_state *S, double dt, orc_sink *sink, 
     amc_step_stats z;
     memset(&z, 0, sizeof z);
     int64_t before = sink ? sink->n : 0;
+    ORC(fp_tolerated) = 0;
     if (P->geometry == AMC_GEOM_CUBE) {
         ORC(drift)(P, S, dt, 0);
         ORC(cube_walls)(P, S);
@@ -554,7 +559,7 @@ int ORC(timestep)(const amc_params *P, orc_state *S, double dt, orc_sink *sink, 
         rc = AMC_ERR_INVALID;
     }
     z.n_paths = sink ? sink->n - before : 0;
-    if (rc == AMC_ERR_FP) z.n_fp_errors = 1;
+    z.n_fp_errors = ORC(fp_tolerated) + (rc == AMC_ERR_FP ? 1 : 0);
     if (st) *st = z;
     return rc;
 }

@@ -725,3 +725,51 @@ def test_baseline_config3_pore_5e5_vs_oracle(Engine, O):
     for key in ("total", "px", "py", "pz"):
         assert np.array_equal(np.sort(rec[key]), np.sort(ref[key])), key
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- count-and-continue option
+def test_tolerated_fp_events_match_oracle(Engine, O):
+    """amc_params.reserved1 bit0 (count and continue, Temp:340-342 semantics for every geometry): a side-wall solve
+    without a real root and a pair with zero relative velocity are counted, leave the particles untouched, and the run
+    goes on — identically on the GPU and in the oracle; without the option both report AMC_ERR_FP."""
+    n = 64
+    rng = np.random.default_rng(4)
+    for mode in (1, 2):
+        p, c = PR.pore_params(n=n)
+        p.detect_mode = mode
+        p.reserved1 = 1
+        pos = np.stack([rng.random(n) * 2e-8 - 1e-8, rng.random(n) * 2e-8 - 1e-8, 1.0e-6 + rng.random(n) * 5e-7])
+        vel = rng.normal(size=(3, n)) * 300.0
+        # particle 0: outside the open-air radius, flying tangentially -> the backward ray never meets the wall (Pore:336)
+        pos[:, 0] = [1.02 * p.R_oa, 0.0, 5.0e-8]
+        vel[:, 0] = [0.0, 300.0, 10.0]
+        # particles 1, 2: overlapping with identical velocities -> a == 0 (Pore:182,185)
+        pos[:, 1] = [0.0, 0.0, 2.0e-6]
+        pos[:, 2] = [0.3 * p.collision_range, 0.0, 2.0e-6]
+        vel[:, 1] = vel[:, 2] = [50.0, -20.0, 10.0]
+        eng = Engine(p)
+        orc = O.Oracle(p, mode="mul")
+        eng.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        orc.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        nfp = 0
+        for s in range(3):
+            st = eng.timestep(c["dt"])
+            rc, so = orc.timestep(c["dt"])
+            assert rc == 0
+            for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"):
+                assert st[k] == so[k], (mode, s, k, st, so)
+            nfp += st["n_fp_errors"]
+            assert_state_equal(eng.download(), orc.state(), ("tolerant", mode, s))
+        assert nfp >= 2
+        eng.close()
+        # strict mode: both sides refuse
+        p.reserved1 = 0
+        eng = Engine(p)
+        orc = O.Oracle(p, mode="mul")
+        eng.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        orc.upload(pos[0], pos[1], pos[2], vel[0], vel[1], vel[2])
+        rc, so = orc.timestep(c["dt"])
+        assert rc != 0
+        with pytest.raises(Exception):
+            eng.timestep(c["dt"])
+        eng.close()

@@ -1,0 +1,69 @@
+"""Long parity run on the GPU box: the HIP path and the CPU oracle advance the same workload side by side; the state
+is compared bit for bit every `chunk` steps and the device histograms with np.histogram of the oracle's completed
+paths at the end.  Writes a JSON summary (committed under profiles/ as evidence).
+
+    python tools/soak.py pore_1e6 1000 100
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from bench import make_workload
+from argon_monte_carlo_amd.engine import Engine
+from oracle import oracle as O
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "pore_1e6"
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+p, c, init = make_workload(workload)
+eng = Engine(p)
+orc = O.Oracle(p, mode="mul", path_capacity=1 << 24)
+eng.upload(*init)
+orc.upload(*init)
+keys = ["x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz", "flag"]
+tot = {}
+otot = {}
+t_gpu = t_cpu = 0.0
+done = 0
+ok = True
+first_bad = None
+while done < steps and ok:
+    k = min(chunk, steps - done)
+    t0 = time.perf_counter()
+    st = eng.run(c["dt"], k)
+    t_gpu += time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(k):
+        rc, so = orc.timestep(c["dt"])
+        if rc != 0:
+            raise SystemExit(f"oracle aborted the step (rc={rc}): the reference would have raised here")
+        for kk in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"):
+            otot[kk] = otot.get(kk, 0) + so[kk]
+    t_cpu += time.perf_counter() - t0
+    for kk in otot:
+        tot[kk] = tot.get(kk, 0) + st[kk]
+    done += k
+    g, o = eng.download(), orc.state()
+    for kk in keys:
+        if not np.array_equal(g[kk], o[kk]):
+            ok = False
+            first_bad = (done, kk, int(np.flatnonzero(g[kk] != o[kk])[0]))
+            break
+    print(f"step {done}: {'equal' if ok else 'DIFFERENT ' + str(first_bad)}  counters gpu={tot} cpu={otot}", flush=True)
+counts, npaths = eng.histograms()
+paths = orc.paths()
+hist_equal = bool(npaths == len(paths))
+for row, key in enumerate(("total", "px", "py", "pz")):
+    ref, _ = np.histogram(paths[key], bins=p.hist_bins, range=(p.hist_lo, p.hist_hi))
+    hist_equal = hist_equal and bool(np.array_equal(counts[row], ref.astype(np.uint64)))
+out = {"workload": workload, "n": int(p.n), "steps": done, "compared_every": chunk, "state_bit_identical": ok,
+       "first_difference": first_bad, "counters_equal": tot == otot, "counters": tot, "completed_paths": int(npaths),
+       "histograms_equal_np_histogram_of_oracle_paths": hist_equal, "gpu_seconds": round(t_gpu, 3),
+       "oracle_seconds_1_core": round(t_cpu, 1)}
+print(json.dumps(out))
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(f"gpurun_out/soak_{workload}_{done}.json", "w"), indent=1)
