@@ -416,6 +416,7 @@ AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
 
 // validation probe of history entry h: its position against every particle outside its cluster.  `cnt` are the
 // sweep counters (LDS inside a resolve kernel, W.ctl in the wide validate kernel), `label` the per-slot labels.
+#define RS_PF 4     // lists whose first element rs_probe prefetches
 AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const int *label, int ns, int cap, int h,
                       double cr2i)
 {
@@ -437,30 +438,73 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
             if (c_hi[k] != c_lo[k]) { lh[2 * k + 1] = amc_list_head(A.B, c_hi[k]); ovh[2 * k + 1] = W.ov_head[c_hi[k]]; }
         }
     }
+    const int nx_me = W.ov_next[h], nx_pa = W.ov_next[h ^ 1];       // to step over my own / my partner's entry without a round trip
+    // The probe is a chain of dependent memory round trips, so the FIRST element of every list (grid and overlay) is
+    // fetched before any is examined; longer lists (rare at ~0.25 particles per cell) continue one element at a time.
+    double4 r0[RS_PF];
+    int os0[RS_PF], og0[RS_PF], on0[RS_PF];
+    double ox0[RS_PF], oy0[RS_PF], oz0[RS_PF];
+#pragma unroll
+    for (int k = 0; k < RS_PF; k++) {
+        if (lh[k] >= 0) r0[k] = A.B.rec[lh[k]];
+        // history entries are allocated in pairs (the two particles of one hit): h ^ 1 is my partner's entry — same
+        // cluster by construction, and for an isolated pair the only other entry nearby: skipped before any load
+        while (ovh[k] >= 0 && (ovh[k] | 1) == (h | 1)) ovh[k] = (ovh[k] == h) ? nx_me : nx_pa;
+        if (ovh[k] >= 0) {
+            const int h2 = ovh[k];
+            os0[k] = W.hist_slot[h2]; og0[k] = W.hist_gen[h2]; on0[k] = W.ov_next[h2];
+            ox0[k] = W.hist_x[h2]; oy0[k] = W.hist_y[h2]; oz0[k] = W.hist_z[h2];
+        }
+    }
+    auto grid_entry = [&](int idx, const double4 &r) {
+        if (idx == pme) return;
+        const double ax = r.x - x, ay = r.y - y, az = r.z - z;
+        if (ax * ax + ay * ay + az * az < cr2i) {
+            const int so = W.slot_of[idx];
+            if (so >= 0 && so < ns && label[so] == lme) return;
+            if (so < 0) rs_claim_slot(W, cnt, cap, idx);
+            rs_add_edge(W, cnt, pme, idx);
+        }
+    };
+    auto overlay_entry = [&](int s2, int gen2, double hx, double hy, double hz) {
+        if (gen2 != W.sl_gen[s2]) return;                 // position of an emulation that was redone since
+        if (label[s2] == lme) return;
+        const double ax = hx - x, ay = hy - y, az = hz - z;
+        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
+    };
     // pre-sweep positions of the particles binned into those cells
-    for (int k = 0; k < 2 * ncell; k++)
-        for (int q = lh[k]; q >= 0;) {
-            const double4 r = A.B.rec[q];
-            const int idx = q;
-            q = amc_rec_next(r);
-            if (idx == pme) continue;
-            const double ax = r.x - x, ay = r.y - y, az = r.z - z;
-            if (ax * ax + ay * ay + az * az < cr2i) {
-                const int so = W.slot_of[idx];
-                if (so >= 0 && so < ns && label[so] == lme) continue;
-                if (so < 0) rs_claim_slot(W, cnt, cap, idx);
-                rs_add_edge(W, cnt, pme, idx);
+#pragma unroll
+    for (int k = 0; k < RS_PF; k++)
+        if (lh[k] >= 0) {
+            grid_entry(lh[k], r0[k]);
+            for (int q = amc_rec_next(r0[k]); q >= 0;) {
+                const double4 r = A.B.rec[q];
+                grid_entry(q, r);
+                q = amc_rec_next(r);
             }
         }
+    for (int k = RS_PF; k < 2 * ncell; k++)
+        for (int q = lh[k]; q >= 0;) {
+            const double4 r = A.B.rec[q];
+            grid_entry(q, r);
+            q = amc_rec_next(r);
+        }
     // new positions of other clusters' members (overlay lists of the same cells)
-    for (int k = 0; k < 2 * ncell; k++)
+#pragma unroll
+    for (int k = 0; k < RS_PF; k++)
+        if (ovh[k] >= 0) {
+            overlay_entry(os0[k], og0[k], ox0[k], oy0[k], oz0[k]);
+            for (int h2 = on0[k]; h2 >= 0;) {
+                if ((h2 | 1) == (h | 1)) { h2 = (h2 == h) ? nx_me : nx_pa; continue; }
+                const int nx = W.ov_next[h2];
+                overlay_entry(W.hist_slot[h2], W.hist_gen[h2], W.hist_x[h2], W.hist_y[h2], W.hist_z[h2]);
+                h2 = nx;
+            }
+        }
+    for (int k = RS_PF; k < 2 * ncell; k++)
         for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
-            if (h2 == h) continue;
-            const int s2 = W.hist_slot[h2];
-            if (W.hist_gen[h2] != W.sl_gen[s2]) continue;     // position of an emulation that was redone since
-            if (label[s2] == lme) continue;
-            const double ax = W.hist_x[h2] - x, ay = W.hist_y[h2] - y, az = W.hist_z[h2] - z;
-            if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
+            if ((h2 | 1) == (h | 1)) continue;
+            overlay_entry(W.hist_slot[h2], W.hist_gen[h2], W.hist_x[h2], W.hist_y[h2], W.hist_z[h2]);
         }
 }
 
@@ -731,6 +775,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         if (!A.allpairs) {
             for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
+            if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[14] += n__ - t_last; }
             for (int h = sh.hist_begin + tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);
         } else {
             // no grid (single cell / small N): brute force against all particles and all history entries
