@@ -166,13 +166,13 @@ void amc_destroy(amc_ctx *c)
                     c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
                     c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
-                    c->W.edge_b, c->W.hist_slot, c->W.hist_x, c->W.hist_y, c->W.hist_z, c->W.ov_head, c->W.ov_next,
+                    c->W.edge_b, c->W.hist, c->W.ov_head, c->W.ov_next,
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
                     c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
-                    c->W.ev_gen, c->W.ev_slot, c->W.hist_gen};
+                    c->W.ev_gen, c->W.ev_slot};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -291,9 +291,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
         for (int k = 0; k < 10; k++) CK(dalloc(&W.cw_d[k], ms));
         CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_slot, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
         CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
-        CK(dalloc(&W.hist_slot, (size_t)W.max_hist)); CK(dalloc(&W.hist_x, (size_t)W.max_hist));
-        CK(dalloc(&W.hist_y, (size_t)W.max_hist)); CK(dalloc(&W.hist_z, (size_t)W.max_hist));
-        CK(dalloc(&W.ov_next, (size_t)W.max_hist)); CK(dalloc(&W.hist_gen, (size_t)W.max_hist));
+        CK(dalloc(&W.hist, (size_t)W.max_hist)); CK(dalloc(&W.ov_next, (size_t)W.max_hist));
         CK(dalloc(&W.ev_phase, (size_t)W.max_events)); CK(dalloc(&W.ev_i, (size_t)W.max_events));
         CK(dalloc(&W.ev_j, (size_t)W.max_events)); CK(dalloc(&W.ev_which, (size_t)W.max_events));
         CK(dalloc(&W.ev_cell, (size_t)W.max_events)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_events));

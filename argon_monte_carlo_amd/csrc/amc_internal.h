@@ -61,14 +61,13 @@ struct amc_resolve_ws {
     double *sl_x, *sl_y, *sl_z, *sl_vx, *sl_vy, *sl_vz, *sl_d, *sl_dx, *sl_dy, *sl_dz;
     uint8_t *sl_flag, *sl_moved, *sl_dirty;
     int *sl_gen, *sl_hits;    // round in which the slot's cluster was last emulated; collisions counted on the slot
-    int *ev_gen, *ev_slot, *hist_gen;   // round tags: results of a re-emulated cluster are superseded, not erased
+    int *ev_gen, *ev_slot;    // round tags: results of a re-emulated cluster are superseded, not erased
     double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
     int *cw_tmp, *cw_pidx, *cw_slot;
     uint8_t *cw_flag, *cw_moved;
     int *edge_a, *edge_b;     // extra merge edges (slots) found by verification
     int max_edges;
-    int *hist_slot;           // position history of the current round: slot and new position
-    double *hist_x, *hist_y, *hist_z;
+    double4 *hist;            // position history of the sweep: (x, y, z, slot | round << 32) per new position
     int max_hist;
     int *ov_head, *ov_next;   // overlay lists of history entries per grid cell ([ncells], [max_hist])
     // events of the current round (completed paths, emitted at commit)

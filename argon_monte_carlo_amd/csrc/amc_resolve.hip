@@ -98,6 +98,15 @@ AMC_DEV void rs_store_work(const rs_work &K, int w, const amc_particle &q)
     K.moved[w] = 1;
 }
 
+// history entry = one 32-byte record (x, y, z, slot | round << 32): one request to write it and one to read it (the
+// validation probes are bound by the number of memory requests a single CU can have in flight)
+AMC_DEV double4 rs_hist_make(double x, double y, double z, int slot, int gen)
+{
+    return make_double4(x, y, z, __longlong_as_double(((long long)gen << 32) | (unsigned int)slot));
+}
+AMC_DEV int rs_hist_slot(const double4 &r) { return (int)(unsigned int)(__double_as_longlong(r.w) & 0xffffffffLL); }
+AMC_DEV int rs_hist_gen(const double4 &r) { return (int)(__double_as_longlong(r.w) >> 32); }
+
 // one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
 // Returns true if the particles moved.
 AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
@@ -124,9 +133,8 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     atomicAdd(&W.sl_hits[si], 1);   // (no value needed back: the thread does not wait for the memory round trip)
     const int h = atomicAdd(&sh->nhist, 2);
     if (h + 1 < W.max_hist) {
-        W.hist_gen[h] = sh->cur_round; W.hist_gen[h + 1] = sh->cur_round;
-        W.hist_slot[h] = sj; W.hist_x[h] = p1.x; W.hist_y[h] = p1.y; W.hist_z[h] = p1.z;
-        W.hist_slot[h + 1] = si; W.hist_x[h + 1] = p2.x; W.hist_y[h + 1] = p2.y; W.hist_z[h + 1] = p2.z;
+        W.hist[h] = rs_hist_make(p1.x, p1.y, p1.z, sj, sh->cur_round);
+        W.hist[h + 1] = rs_hist_make(p2.x, p2.y, p2.z, si, sh->cur_round);
     } else {
         sh->ovf = 1;
     }
@@ -421,10 +429,11 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
                       double cr2i)
 {
     const amc_resolve_ws &W = A.W;
-    const int sme = W.hist_slot[h];
+    const double4 me = W.hist[h];
+    const int sme = rs_hist_slot(me);
     const int pme = W.sl_p[sme];
     const int lme = label[sme];
-    const double x = W.hist_x[h], y = W.hist_y[h], z = W.hist_z[h];
+    const double x = me.x, y = me.y, z = me.z;
     // only the cells overlapped by the collision_range box around the new position can hold a partner (2 to 3 on
     // average): fetch their list heads and overlay heads first, then the entries
     int c_lo[4], c_hi[4], lh[8], ovh[8];
@@ -441,9 +450,8 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const int nx_me = W.ov_next[h], nx_pa = W.ov_next[h ^ 1];       // to step over my own / my partner's entry without a round trip
     // The probe is a chain of dependent memory round trips, so the FIRST element of every list (grid and overlay) is
     // fetched before any is examined; longer lists (rare at ~0.25 particles per cell) continue one element at a time.
-    double4 r0[RS_PF];
-    int os0[RS_PF], og0[RS_PF], on0[RS_PF];
-    double ox0[RS_PF], oy0[RS_PF], oz0[RS_PF];
+    double4 r0[RS_PF], o0[RS_PF];
+    int on0[RS_PF];
 #pragma unroll
     for (int k = 0; k < RS_PF; k++) {
         if (lh[k] >= 0) r0[k] = A.B.rec[lh[k]];
@@ -452,8 +460,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         while (ovh[k] >= 0 && (ovh[k] | 1) == (h | 1)) ovh[k] = (ovh[k] == h) ? nx_me : nx_pa;
         if (ovh[k] >= 0) {
             const int h2 = ovh[k];
-            os0[k] = W.hist_slot[h2]; og0[k] = W.hist_gen[h2]; on0[k] = W.ov_next[h2];
-            ox0[k] = W.hist_x[h2]; oy0[k] = W.hist_y[h2]; oz0[k] = W.hist_z[h2];
+            o0[k] = W.hist[h2]; on0[k] = W.ov_next[h2];
         }
     }
     auto grid_entry = [&](int idx, const double4 &r) {
@@ -466,10 +473,11 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
             rs_add_edge(W, cnt, pme, idx);
         }
     };
-    auto overlay_entry = [&](int s2, int gen2, double hx, double hy, double hz) {
-        if (gen2 != W.sl_gen[s2]) return;                 // position of an emulation that was redone since
+    auto overlay_entry = [&](const double4 &o) {
+        const int s2 = rs_hist_slot(o);
+        if (rs_hist_gen(o) != W.sl_gen[s2]) return;       // position of an emulation that was redone since
         if (label[s2] == lme) return;
-        const double ax = hx - x, ay = hy - y, az = hz - z;
+        const double ax = o.x - x, ay = o.y - y, az = o.z - z;
         if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
     };
     // pre-sweep positions of the particles binned into those cells
@@ -493,25 +501,26 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
 #pragma unroll
     for (int k = 0; k < RS_PF; k++)
         if (ovh[k] >= 0) {
-            overlay_entry(os0[k], og0[k], ox0[k], oy0[k], oz0[k]);
+            overlay_entry(o0[k]);
             for (int h2 = on0[k]; h2 >= 0;) {
                 if ((h2 | 1) == (h | 1)) { h2 = (h2 == h) ? nx_me : nx_pa; continue; }
                 const int nx = W.ov_next[h2];
-                overlay_entry(W.hist_slot[h2], W.hist_gen[h2], W.hist_x[h2], W.hist_y[h2], W.hist_z[h2]);
+                overlay_entry(W.hist[h2]);
                 h2 = nx;
             }
         }
     for (int k = RS_PF; k < 2 * ncell; k++)
         for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
             if ((h2 | 1) == (h | 1)) continue;
-            overlay_entry(W.hist_slot[h2], W.hist_gen[h2], W.hist_x[h2], W.hist_y[h2], W.hist_z[h2]);
+            overlay_entry(W.hist[h2]);
         }
 }
 
 AMC_DEV int rs_hist_cell(const rs_args &A, const amc_grid &G, int h)
 {
     int cx, cy, cz;
-    amc_grid_coords(G, A.W.hist_x[h], A.W.hist_y[h], A.W.hist_z[h], cx, cy, cz);
+    const double4 r = A.W.hist[h];
+    amc_grid_coords(G, r.x, r.y, r.z, cx, cy, cz);
     return amc_grid_cell(G, cx, cy, cz, nullptr);
 }
 
@@ -783,9 +792,10 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             for (long long w = tid; w < (long long)(nh - hb) * A.n; w += RS_T) {
                 const int h = hb + (int)(w / A.n);
                 const int idx = (int)(w % A.n);
-                const int sme = W.hist_slot[h];
+                const double4 hr = W.hist[h];
+                const int sme = rs_hist_slot(hr);
                 if (idx == V.p[sme]) continue;
-                const double ex = A.S.x[idx] - W.hist_x[h], ey = A.S.y[idx] - W.hist_y[h], ez = A.S.z[idx] - W.hist_z[h];
+                const double ex = A.S.x[idx] - hr.x, ey = A.S.y[idx] - hr.y, ez = A.S.z[idx] - hr.z;
                 if (ex * ex + ey * ey + ez * ez < cr2i) {
                     const int so = W.slot_of[idx];
                     if (so >= 0 && so < ns && V.label[so] == V.label[sme]) continue;
@@ -796,10 +806,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             for (long long w = tid; w < (long long)(nh - hb) * nh; w += RS_T) {
                 const int h = hb + (int)(w / nh), h2 = (int)(w % nh);
                 if (h2 >= h) continue;
-                const int s1 = W.hist_slot[h], s2 = W.hist_slot[h2];
-                if (W.hist_gen[h2] != W.sl_gen[s2]) continue;
+                const double4 ha = W.hist[h], hb2 = W.hist[h2];
+                const int s1 = rs_hist_slot(ha), s2 = rs_hist_slot(hb2);
+                if (rs_hist_gen(hb2) != W.sl_gen[s2]) continue;
                 if (V.label[s1] == V.label[s2]) continue;
-                const double ex = W.hist_x[h2] - W.hist_x[h], ey = W.hist_y[h2] - W.hist_y[h], ez = W.hist_z[h2] - W.hist_z[h];
+                const double ex = hb2.x - ha.x, ey = hb2.y - ha.y, ez = hb2.z - ha.z;
                 if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, V.p[s1], V.p[s2]);
             }
         }
