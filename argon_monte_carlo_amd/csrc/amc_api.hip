@@ -168,7 +168,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
                     c->W.edge_b, c->W.hist, c->W.ov_head, c->W.ov_next,
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
+                    c->d_edges, c->d_cnt, c->d_banks, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
@@ -219,7 +219,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
-    c->d_lay = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
+    c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr;
     c->mg_count_pp = true;
     c->lazy_pending = false;
@@ -297,11 +297,14 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.ev_cell, (size_t)W.max_events)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_events));
         CK(dalloc(&W.ev_gen, (size_t)W.max_events)); CK(dalloc(&W.ev_slot, (size_t)W.max_events));
         // outputs
-        long long mp = p->max_paths > 0 ? p->max_paths : (1LL << 20);
+        long long mp = p->max_paths > 0 ? p->max_paths : (p->max_paths < 0 ? 0 : (1LL << 20));   // < 0: histograms only
         if (mp > 0x7fffffff) mp = 0x7fffffff;
-        CK(dalloc(&c->d_rec, (size_t)mp));
+        if (mp > 0) CK(dalloc(&c->d_rec, (size_t)mp));
         CK(dalloc(&c->d_cnt, 1));
         CK(hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
+        CK(dalloc(&c->d_banks, AMC_COUNTER_BANKS));
+        CK(hipMemsetAsync(c->d_banks, 0, sizeof(amc_counter_bank) * AMC_COUNTER_BANKS, c->stream));
+        c->out.banks = c->d_banks;
         c->out.rec = c->d_rec; c->out.cap = (unsigned)mp; c->out.cnt = c->d_cnt; c->out.step = 0;
         c->out.nbins = 0; c->out.hist = nullptr; c->out.edges = nullptr; c->out.lo = p->hist_lo; c->out.hi = p->hist_hi;
         if (p->hist_bins > 0 && p->hist_hi > p->hist_lo) {
@@ -447,11 +450,22 @@ struct amc_stage {
     }
 };
 
+static void fold_banks(amc_dev_counters *h, const amc_counter_bank *b)
+{
+    for (int k = 0; k < AMC_COUNTER_BANKS; k++) {
+        h->n_wall += b[k].n_wall; h->n_paths += b[k].n_paths; h->n_paths_total += b[k].n_paths_total;
+        h->n_fp_errors += b[k].n_fp_errors;
+    }
+}
+
 static int read_counters(amc_ctx *c, amc_dev_counters *h)
 {
+    amc_counter_bank banks[AMC_COUNTER_BANKS];
     amc_stage st(c);
     AMC_HIP(c, st.get(h, c->d_cnt, sizeof *h));
+    AMC_HIP(c, st.get(banks, c->d_banks, sizeof banks));
     AMC_HIP(c, st.finish());
+    fold_banks(h, banks);
     return AMC_OK;
 }
 
@@ -648,6 +662,7 @@ int amc_reset_outputs(amc_ctx *c)
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->d_hist) AMC_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(uint64_t) * 4 * c->out.nbins, c->stream));
     AMC_HIP(c, hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
+    AMC_HIP(c, hipMemsetAsync(c->d_banks, 0, sizeof(amc_counter_bank) * AMC_COUNTER_BANKS, c->stream));
     AMC_HIP(c, hipStreamSynchronize(c->stream));
     memset(&c->h_prev, 0, sizeof c->h_prev);
     c->out.step = 0;

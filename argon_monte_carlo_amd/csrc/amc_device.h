@@ -25,10 +25,26 @@ struct amc_dev_counters {
     int pad;
 };
 
+// Per-event counters are BANKED: returning or not, atomics on one word from different waves complete one every ~12 ns
+// (tools/ubench_sameaddr.hip), which at ~10^3 wall hits per step is a serial chain of tens of microseconds inside a
+// streaming kernel.  Each wave adds to the bank of its (block, wave) id, one 64-byte line per bank; read_counters()
+// folds the banks into amc_dev_counters on the host.
+#define AMC_COUNTER_BANKS 64
+struct amc_counter_bank {
+    unsigned long long n_wall, n_paths, n_paths_total, n_fp_errors, pad[4];
+};
+// (readfirstlane: the id is the same for all lanes of a wave; telling the compiler so keeps its wave-level combining of
+// atomics on a uniform address, which otherwise turns one atomic per wave into one per lane)
+AMC_DEV int amc_bank_id()
+{
+    return __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 8u + (threadIdx.x >> 6)) & (AMC_COUNTER_BANKS - 1)));
+}
+
 // where completed paths go: a record buffer (optional) + the four np.histogram-compatible histograms
 struct amc_out {
-    amc_path_record *rec;
+    amc_path_record *rec;               // nullptr: no records, histograms only
     unsigned int cap;
+    amc_counter_bank *banks;            // [AMC_COUNTER_BANKS]
     unsigned long long *hist;           // [4][nbins]
     const double *edges;                // [nbins+1] = np.linspace(lo, hi, nbins+1) (kept for reference; recomputed on the fly)
     double bin_step;                    // (hi - lo) / nbins: edge k = lo + k * bin_step, edge nbins = hi — np.linspace's formula
@@ -57,8 +73,9 @@ AMC_DEV int amc_hist_bin(const amc_out &o, double v)
 AMC_DEV void amc_emit(const amc_out &o, int phase, long long cell, int i, int j, int which, double tot, double px,
                       double py, double pz)
 {
-    atomicAdd(&o.cnt->n_paths, 1ULL);
-    atomicAdd(&o.cnt->n_paths_total, 1ULL);
+    amc_counter_bank &bank = o.banks[amc_bank_id()];
+    atomicAdd(&bank.n_paths, 1ULL);
+    atomicAdd(&bank.n_paths_total, 1ULL);
     if (o.hist) {
         int b;
         if ((b = amc_hist_bin(o, tot)) >= 0) atomicAdd(&o.hist[0 * o.nbins + b], 1ULL);

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, a
     if (n < 0) n = min(*R.count, R.cap);        // device-RNG mode: the host never saw the count
     if (k >= n) return;
     dpz[k] = 0; dE[k] = 0;
-    if (!R.ok[k]) { atomicAdd(&O.cnt->n_fp_errors, 1ULL); atomicAdd(&O.cnt->n_wall, 1ULL); return; }
+    if (!R.ok[k]) { atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, 1ULL); atomicAdd(&O.banks[amc_bank_id()].n_wall, 1ULL); return; }
     const int p = R.idx[k];
     const double m = P.argon_mass;
     const double alpha = (case_id == 5) ? P.alpha_gap : P.alpha_coated;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, a
     S.d[p] = 0; S.dx[p] = 0; S.dy[p] = 0; S.dz[p] = 0;                                       // Temp:398-401
     S.x[p] = R.contact[3 * k]; S.y[p] = R.contact[3 * k + 1]; S.z[p] = R.contact[3 * k + 2];   // Temp:402
     S.vx[p] = wvx; S.vy[p] = wvy; S.vz[p] = wvz;                                             // Temp:403
-    atomicAdd(&O.cnt->n_wall, 1ULL);                                                         // Temp:411,482,552
+    atomicAdd(&O.banks[amc_bank_id()].n_wall, 1ULL);                                         // Temp:411,482,552
 }
 
 static temp_records make_records(amc_ctx *c)

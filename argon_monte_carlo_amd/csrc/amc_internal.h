@@ -125,6 +125,7 @@ struct amc_ctx {
     unsigned long long *d_hist;
     double *d_edges;
     amc_dev_counters *d_cnt;
+    amc_counter_bank *d_banks;   // banked per-event counters, folded into the copy read_counters() returns
     amc_dev_counters h_prev;  // snapshot used to report per-step deltas
     long long *d_dbg;         // resolve phase timers (diagnostic, enabled by AMC_DEBUG_RESOLVE=1)
     // profiling

@@ -586,7 +586,8 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     rs_slots V;
     V.p = W.sl_p;
     unsigned char *vdirty;
-    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS; vdirty = s_dirty; }
+    // (the slot arrays in global memory hold W.max_slots entries: labels in LDS must not let validation claim more)
+    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS < W.max_slots ? RS_NS : W.max_slots; vdirty = s_dirty; }
     else { V.label = W.sl_label; V.size = W.sl_tmp; V.cap = W.max_slots; vdirty = W.sl_dirty; }
     // grid layer tables -> LDS (every validation probe reads them)
     amc_grid G = A.G;

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         amc_list_insert(G, B, (int)p, q.x, q.y, q.z, &outside);
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
     }
-    if (nwall) atomicAdd(&O.cnt->n_wall, (unsigned long long)nwall);
-    if (nerr) atomicAdd(&O.cnt->n_fp_errors, (unsigned long long)nerr);
+    if (nwall) atomicAdd(&O.banks[amc_bank_id()].n_wall, (unsigned long long)nwall);
+    if (nerr) atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, (unsigned long long)nerr);
     if (noob) atomicAdd(bounds_slot ? &O.cnt->n_oob_pp : &O.cnt->n_oob_walls, (unsigned long long)noob);
 }
 

@@ -58,6 +58,7 @@ def make_workload(name, n_override=None, device=0):
         init = IC.pore_ic(p, c, seed=17)
     # count-and-continue on a degenerate wall/contact solve (Temp:340-342 semantics) instead of aborting like Pore:336-338
     p.reserved1 = 1
+    p.max_paths = -1                # completed paths go into the device histograms only (no per-path records to drain)
     return p, c, init
 
 

@@ -108,7 +108,8 @@ typedef struct amc_params {
     int32_t device;               /* HIP device ordinal                                                */
     int32_t detect_mode;          /* 0 auto, 1 binned (cell grid), 2 tiled all-pairs                   */
     int64_t max_candidates;       /* capacity of the candidate-pair list; 0 = default                  */
-    int64_t max_paths;            /* capacity of the completed-path record buffer; 0 = default         */
+    int64_t max_paths;            /* capacity of the completed-path record buffer; 0 = default (2^20), < 0 = no
+                                   * records at all (completed paths only go into the device histograms)     */
 } amc_params;
 
 /* Per-step counters.  n_collisions = what the reference accumulates in num_collisions_per_step (Pore:424,
