@@ -309,8 +309,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         c->out.nbins = 0; c->out.hist = nullptr; c->out.edges = nullptr; c->out.lo = p->hist_lo; c->out.hi = p->hist_hi;
         if (p->hist_bins > 0 && p->hist_hi > p->hist_lo) {
             const int nb = p->hist_bins;
-            CK(dalloc(&c->d_hist, (size_t)4 * nb));
-            CK(hipMemsetAsync(c->d_hist, 0, sizeof(unsigned long long) * 4 * nb, c->stream));
+            CK(dalloc(&c->d_hist, (size_t)4 * nb * AMC_COUNTER_BANKS));
+            CK(hipMemsetAsync(c->d_hist, 0, sizeof(unsigned long long) * 4 * nb * AMC_COUNTER_BANKS, c->stream));
             CK(dalloc(&c->d_edges, (size_t)nb + 1));
             // np.linspace(lo, hi, nb+1): start + k*step with step = (hi-lo)/nb, last element forced to hi
             std::vector<double> ed(nb + 1);
@@ -647,11 +647,21 @@ int amc_histograms(amc_ctx *c, uint64_t *counts, uint64_t *n_paths_total)
     AMC_HIP(c, hipSetDevice(c->device));
     if (counts) {
         if (!c->d_hist) return amc_fail(c, AMC_ERR_STATE, "histograms disabled (hist_bins == 0)");
-        AMC_HIP(c, hipMemcpyAsync(counts, c->d_hist, sizeof(uint64_t) * 4 * c->out.nbins, hipMemcpyDeviceToHost, c->stream));
+    }
+    std::vector<uint64_t> banks;
+    if (counts) {
+        banks.resize((size_t)4 * c->out.nbins * AMC_COUNTER_BANKS);
+        AMC_HIP(c, hipMemcpyAsync(banks.data(), c->d_hist, sizeof(uint64_t) * banks.size(), hipMemcpyDeviceToHost, c->stream));
     }
     amc_dev_counters now;
-    int rc = read_counters(c, &now);
+    int rc = read_counters(c, &now);        // (synchronises the stream)
     if (rc) return rc;
+    if (counts) {
+        const size_t m = (size_t)4 * c->out.nbins;
+        for (size_t k = 0; k < m; k++) counts[k] = 0;
+        for (int b = 0; b < AMC_COUNTER_BANKS; b++)
+            for (size_t k = 0; k < m; k++) counts[k] += banks[(size_t)b * m + k];
+    }
     if (n_paths_total) *n_paths_total = now.n_paths_total;
     return AMC_OK;
 }
@@ -660,7 +670,7 @@ int amc_reset_outputs(amc_ctx *c)
 {
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
-    if (c->d_hist) AMC_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(uint64_t) * 4 * c->out.nbins, c->stream));
+    if (c->d_hist) AMC_HIP(c, hipMemsetAsync(c->d_hist, 0, sizeof(uint64_t) * 4 * c->out.nbins * AMC_COUNTER_BANKS, c->stream));
     AMC_HIP(c, hipMemsetAsync(c->d_cnt, 0, sizeof(amc_dev_counters), c->stream));
     AMC_HIP(c, hipMemsetAsync(c->d_banks, 0, sizeof(amc_counter_bank) * AMC_COUNTER_BANKS, c->stream));
     AMC_HIP(c, hipStreamSynchronize(c->stream));

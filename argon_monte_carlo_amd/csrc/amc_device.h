@@ -45,7 +45,7 @@ struct amc_out {
     amc_path_record *rec;               // nullptr: no records, histograms only
     unsigned int cap;
     amc_counter_bank *banks;            // [AMC_COUNTER_BANKS]
-    unsigned long long *hist;           // [4][nbins]
+    unsigned long long *hist;           // [AMC_COUNTER_BANKS][4][nbins], summed over the banks on the host
     const double *edges;                // [nbins+1] = np.linspace(lo, hi, nbins+1) (kept for reference; recomputed on the fly)
     double bin_step;                    // (hi - lo) / nbins: edge k = lo + k * bin_step, edge nbins = hi — np.linspace's formula
     int nbins;
@@ -77,11 +77,14 @@ AMC_DEV void amc_emit(const amc_out &o, int phase, long long cell, int i, int j,
     atomicAdd(&bank.n_paths, 1ULL);
     atomicAdd(&bank.n_paths_total, 1ULL);
     if (o.hist) {
+        // free paths pile up in a few low bins: one copy of the histograms per counter bank keeps the chains of
+        // same-address atomics short (they cost 15 of the wide commit kernel's 24 us at N = 1e6 otherwise)
+        unsigned long long *hb = o.hist + (size_t)amc_bank_id() * 4 * (size_t)o.nbins;
         int b;
-        if ((b = amc_hist_bin(o, tot)) >= 0) atomicAdd(&o.hist[0 * o.nbins + b], 1ULL);
-        if ((b = amc_hist_bin(o, px)) >= 0) atomicAdd(&o.hist[1 * o.nbins + b], 1ULL);
-        if ((b = amc_hist_bin(o, py)) >= 0) atomicAdd(&o.hist[2 * o.nbins + b], 1ULL);
-        if ((b = amc_hist_bin(o, pz)) >= 0) atomicAdd(&o.hist[3 * o.nbins + b], 1ULL);
+        if ((b = amc_hist_bin(o, tot)) >= 0) atomicAdd(&hb[0 * o.nbins + b], 1ULL);
+        if ((b = amc_hist_bin(o, px)) >= 0) atomicAdd(&hb[1 * o.nbins + b], 1ULL);
+        if ((b = amc_hist_bin(o, py)) >= 0) atomicAdd(&hb[2 * o.nbins + b], 1ULL);
+        if ((b = amc_hist_bin(o, pz)) >= 0) atomicAdd(&hb[3 * o.nbins + b], 1ULL);
     }
     if (o.rec) {
         unsigned int k = atomicAdd(&o.cnt->path_count, 1u);

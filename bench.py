@@ -59,6 +59,8 @@ def make_workload(name, n_override=None, device=0):
     # count-and-continue on a degenerate wall/contact solve (Temp:340-342 semantics) instead of aborting like Pore:336-338
     p.reserved1 = 1
     p.max_paths = -1                # completed paths go into the device histograms only (no per-path records to drain)
+    if os.environ.get("AMC_BENCH_NOHIST"):
+        p.hist_bins = 0             # experiment: no histogram atomics at all
     return p, c, init
 
 
