@@ -525,7 +525,9 @@ static int enqueue_sweep(amc_ctx *c, bool counted = false, bool defer_commit = f
 }
 
 
-static int enqueue_step(amc_ctx *c, double dt)
+// fold_prev_bounds: the previous step of the same amc_run left its post-sweep bounds check to this step's streaming
+// pass; defer_bounds: leave this step's to the next one (the caller runs it separately after the last step)
+static int enqueue_step(amc_ctx *c, double dt, bool fold_prev_bounds = false, bool defer_bounds = false)
 {
     const int g = c->P.geometry;
     int rc;
@@ -534,12 +536,13 @@ static int enqueue_step(amc_ctx *c, double dt)
     } else if (g == AMC_GEOM_CUBE || g == AMC_GEOM_PORE) {
         // the streaming pass also counts the particles into the detection grid when it covers all of them
         const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
-        const int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
+        int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
+        if (fold_prev_bounds && g == AMC_GEOM_PORE) st |= AMC_ST_BOUNDS_PRE;
         AMC_HIP(c, amc_launch_stream(c, dt, st, 0, fuse));
         // the scattered commit is deferred: the next streaming pass over all particles (the bounds check for the pore,
         // the next step's drift for the cube) picks the results up through slot_of[]
         if ((rc = enqueue_sweep(c, fuse, c->lo == 0 && c->hi == c->n))) return rc;
-        if (g == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
+        if (g == AMC_GEOM_PORE && !defer_bounds) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
     } else {
         return amc_fail(c, AMC_ERR_INVALID, "energised walls need the host handshake: use the Python driver (amc_wall_hits/apply)");
     }
@@ -562,8 +565,10 @@ int amc_run(amc_ctx *c, double dt, int64_t nsteps, amc_step_stats *sum)
     if (!c) return AMC_ERR_INVALID;
     if (!c->uploaded) return amc_fail(c, AMC_ERR_STATE, "amc_run before amc_upload");
     AMC_HIP(c, hipSetDevice(c->device));
+    // inside the run only the last step needs its own post-sweep bounds pass (needs the whole range in one context)
+    const bool fold = c->P.geometry == AMC_GEOM_PORE && c->lo == 0 && c->hi == c->n && !c->allpairs;
     for (int64_t s = 0; s < nsteps; s++) {
-        int rc = enqueue_step(c, dt);
+        int rc = enqueue_step(c, dt, fold && s > 0, fold && s + 1 < nsteps);
         if (rc) return rc;
     }
     return finish_stats(c, sum);

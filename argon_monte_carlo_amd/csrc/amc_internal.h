@@ -169,6 +169,7 @@ void amc_prof_collect(amc_ctx *c);
 #define AMC_ST_DRIFT 1
 #define AMC_ST_WALLS 2
 #define AMC_ST_BOUNDS 4
+#define AMC_ST_BOUNDS_PRE 8     // the PREVIOUS step's bounds check after its sweep (Pore:550), folded into this pass
 
 // launchers (each enqueues on c->stream; returns hipError_t of the launch)
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin = false);

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
             }
         }
     }
+    // Pore:550 of the previous step: nothing happens between that bounds check and this step's drift, and it touches
+    // only the particle itself, so inside a multi-step run it rides along with this pass instead of a pass of its own
+    int noob_pre = 0;
+    if ((stages & AMC_ST_BOUNDS_PRE) && GEOM != AMC_GEOM_CUBE)
+        noob_pre = amc_bounds(P, q.x, q.y, q.z, GEOM == AMC_GEOM_PORE_ENERGISED);
     double px = q.x, py = q.y, pz = q.z;          // prior_*_vals (Pore:427-429)
     const bool wr_acc = need_acc || force;
 
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
     if (nwall) atomicAdd(&O.banks[amc_bank_id()].n_wall, (unsigned long long)nwall);
     if (nerr) atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, (unsigned long long)nerr);
     if (noob) atomicAdd(bounds_slot ? &O.cnt->n_oob_pp : &O.cnt->n_oob_walls, (unsigned long long)noob);
+    if (noob_pre) atomicAdd(&O.cnt->n_oob_pp, (unsigned long long)noob_pre);
 }
 
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin)
