@@ -424,6 +424,117 @@ AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
 
 // validation probe of history entry h: its position against every particle outside its cluster.  `cnt` are the
 // sweep counters (LDS inside a resolve kernel, W.ctl in the wide validate kernel), `label` the per-slot labels.
+// ---- the same emulation, run by a whole wave for ONE cluster -------------------------------------------------------------
+// A cluster is emulated by a single thread of control (the order of the pair tests is the reference's), and with one lane
+// doing it every load from the working set is a full LDS round trip and every instruction a wave-wide issue.  What does
+// not depend on the order — finding the next layer that holds two members (one lane per member PAIR, then a wave
+// minimum), taking the membership masks of all members, finding the members' pore cells — is spread over the lanes here;
+// only the pair tests of a cell stay on lane 0.  Control flow is uniform; the lanes meet at wave-level fences.
+#define RS_COOP_MAX 11      // members: 55 pairs fit the 64 lanes
+AMC_DEV void rs_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+AMC_DEV int rs_wave_min_nonneg(int v)       // minimum over the lanes of the values >= 0, -1 if there is none
+{
+    unsigned int u = v < 0 ? 0xffffffffu : (unsigned int)v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int t = (unsigned int)__shfl_xor((int)u, o, 64);
+        u = t < u ? t : u;
+    }
+    return u == 0xffffffffu ? -1 : (int)u;
+}
+// lane's pair (a > c) of the cluster [b, e), or a = -1 for lanes beyond the number of pairs
+AMC_DEV void rs_lane_pair(int lane, int m, int &a, int &c)
+{
+    a = -1; c = -1;
+    int k = lane;
+    for (int i = 1; i < m; i++) {
+        if (k < i) { a = i; c = k; return; }
+        k -= i;
+    }
+}
+AMC_DEV int rs_next_layer_coop(const rs_work &K, int b, int pa, int pc, const double *v, int need, double d, double inv_d,
+                               double ov, int n, int from)
+{
+    int l = -1;
+    if (pa >= 0 && (K.tmp[b + pa] & need) == need && (K.tmp[b + pc] & need) == need)
+        l = rs_next_common(v[b + pa], v[b + pc], d, inv_d, ov, n, from);
+    return rs_wave_min_nonneg(l);
+}
+
+AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
+{
+    const amc_params &P = A.P;
+    const int lane = threadIdx.x & 63, m = e - b;
+    const int w = b + lane;                 // my member (lanes < m)
+    int pa, pc;
+    rs_lane_pair(lane, m, pa, pc);
+    if (P.geometry == AMC_GEOM_CELL) {
+        if (lane == 0)
+            for (int a = b + 1; a < e; a++)                                                 // Pore:168-169
+                for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
+        rs_wave_sync();
+    } else if (P.geometry == AMC_GEOM_CUBE) {
+        // Cube:231-238, structure as in rs_emulate_generic (stale in_x / in_y / in_z masks in K.tmp bit 0/1/2)
+        for (int lx = rs_next_layer_coop(K, b, pa, pc, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
+             lx = rs_next_layer_coop(K, b, pa, pc, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1)) {
+            const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;               // Cube:233
+            if (lane < m) K.tmp[w] = ((xlo < K.x[w]) && (K.x[w] < xhi)) ? 1 : 0;
+            rs_wave_sync();
+            for (int ly = rs_next_layer_coop(K, b, pa, pc, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
+                 ly = rs_next_layer_coop(K, b, pa, pc, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1)) {
+                const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;           // Cube:235
+                if (lane < m) {
+                    const int t = K.tmp[w] & 1;
+                    K.tmp[w] = t | ((t && (ylo < K.y[w]) && (K.y[w] < yhi)) ? 2 : 0);
+                }
+                rs_wave_sync();
+                for (int lz = rs_next_layer_coop(K, b, pa, pc, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
+                     lz = rs_next_layer_coop(K, b, pa, pc, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1)) {
+                    const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;       // Cube:237
+                    if (lane < m) {
+                        const int t = K.tmp[w] & 3;
+                        K.tmp[w] = t | ((t == 3 && (zlo < K.z[w]) && (K.z[w] < zhi)) ? 4 : 0);
+                    }
+                    rs_wave_sync();
+                    if (lane == 0) {
+                        const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
+                        for (int a = b + 1; a < e; a++) {
+                            if (K.tmp[a] != 7) continue;
+                            for (int c = b; c < a; c++)
+                                if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
+                        }
+                    }
+                    rs_wave_sync();
+                }
+            }
+        }
+    } else {
+        for (int g = 0; g < 8; g++) {                                                        // Pore:522-524
+            const int gx = g >> 2, gy = (g >> 1) & 1, gz = g & 1;
+            int cell = -1;
+            if (lane < m) {                                                                  // membership at gather time
+                cell = rs_pore_cell(P, K.x[w], K.y[w], K.z[w], gx, gy, gz);
+                K.tmp[w] = cell;
+            }
+            const int cnt = __popcll(__ballot(cell >= 0));
+            rs_wave_sync();
+            if (cnt < 2) continue;
+            if (lane == 0)
+                for (int a = b + 1; a < e; a++) {
+                    const int ca = K.tmp[a];
+                    if (ca < 0) continue;
+                    for (int c = b; c < a; c++)
+                        if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
+                }
+            rs_wave_sync();
+        }
+    }
+}
+
 #define RS_PF 4     // lists whose first element rs_probe prefetches
 AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const int *label, int ns, int cap, int h,
                       double cr2i)
@@ -706,13 +817,27 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[2] += n__ - t_last; t_last = n__; }
-            if (w < nc) {
-                const unsigned lab = (unsigned)(sorted[w] >> 32);
-                if (!(w > 0 && (unsigned)(sorted[w - 1] >> 32) == lab)) {        // cluster head
-                    int e = w + 1;
+            // One or two clusters (the usual case): one after the other, each by the whole wave (rs_emulate_coop; uniform
+            // control flow, every lane walks the same list).  More: one lane per cluster head — the lanes then run the
+            // same code side by side on different clusters, which beats taking the clusters in turn.
+            const bool is_head = w < nc && !(w > 0 && (unsigned)(sorted[w - 1] >> 32) == (unsigned)(sorted[w] >> 32));
+            const int nheads = __popcll(__ballot(is_head));
+            if (nheads <= 2) {
+                for (int w0 = 0; w0 < nc;) {
+                    const unsigned lab = (unsigned)(sorted[w0] >> 32);
+                    int e = w0 + 1;
                     while (e < nc && (unsigned)(sorted[e] >> 32) == lab) e++;
-                    if (e - w >= 2) rs_emulate_generic(A, &sh, K, w, e);
+                    if (e - w0 >= 2) {
+                        if (e - w0 <= RS_COOP_MAX) rs_emulate_coop(A, &sh, K, w0, e);
+                        else if (w == 0) rs_emulate_generic(A, &sh, K, w0, e);
+                    }
+                    w0 = e;
                 }
+            } else if (is_head) {
+                const unsigned lab = (unsigned)(sorted[w] >> 32);
+                int e = w + 1;
+                while (e < nc && (unsigned)(sorted[e] >> 32) == lab) e++;
+                if (e - w >= 2) rs_emulate_generic(A, &sh, K, w, e);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
