@@ -25,615 +25,7 @@
 // set is a few hundred pairs, so the cost is latency, not throughput.  Everything that is scattered memory traffic
 // is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and the
 // first round's validation probes and the commit scatter are separate wide kernels.
-#include "amc_grid_dev.h"
-
-#define RS_T 512
-#define RS_SORT_LDS 2048       // complex-cluster members sorted in LDS up to this many
-#define RS_POOL 256            // complex-cluster working set held in LDS up to this many members
-#define RS_MAX_ROUNDS 256
-#define AMC_CR2_INFLATE (1.0 + 1.0e-9)
-
-struct rs_args {
-    amc_params P;
-    amc_state S;
-    amc_grid G;
-    amc_lists B;
-    amc_resolve_ws W;
-    amc_out O;
-    long long n;
-    int allpairs;
-    int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
-    int defer_commit;         // leave the results in the slot arrays: the next streaming pass (or k_apply) writes them
-    int apply_only;           // k_commit: only write deferred results (amc_flush)
-    int allow_mono;           // small sweeps may run validation + commit inside resolve_A
-    int force_mono;           // the host launched ONLY this kernel (it expects a small sweep): do everything here
-    int *host_ncand;          // host-mapped word: candidate count of this sweep, read (lagging) by the host to pick the launch plan (saves three kernels' latency)
-    int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
-    long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
-    double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
-    long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
-};
-
-// counters of one sweep; lives in LDS while a resolve kernel runs and in W.ctl (global) between the kernels
-struct rs_shared {
-    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
-    int rounds, ncand, active, ok, edges_done;
-    int lazy_ns;              // slots whose results are still only in the slot arrays (deferred commit)
-    int nslots0;              // slots that existed (and have labels in W.sl_label) when a resolve kernel handed over
-    int hist_begin;           // first history entry of the current round (older ones were validated already)
-    int cur_round;
-};
-
-// working set of the multi-particle clusters (LDS pool or global fallback), indexed by sorted rank
-struct rs_work {
-    double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
-    int *tmp, *pidx, *slot;     // scratch, particle index, slot index of each member
-    uint8_t *flag, *moved;
-};
-
-AMC_DEV amc_particle rs_load_particle(const amc_state &S, int p)
-{
-    amc_particle q;
-    q.x = S.x[p]; q.y = S.y[p]; q.z = S.z[p]; q.vx = S.vx[p]; q.vy = S.vy[p]; q.vz = S.vz[p];
-    q.d = S.d[p]; q.dx = S.dx[p]; q.dy = S.dy[p]; q.dz = S.dz[p]; q.flag = S.flag[p] != 0;
-    return q;
-}
-AMC_DEV void rs_store_slot(const amc_resolve_ws &W, int s, const amc_particle &q)
-{
-    W.sl_x[s] = q.x; W.sl_y[s] = q.y; W.sl_z[s] = q.z; W.sl_vx[s] = q.vx; W.sl_vy[s] = q.vy; W.sl_vz[s] = q.vz;
-    W.sl_d[s] = q.d; W.sl_dx[s] = q.dx; W.sl_dy[s] = q.dy; W.sl_dz[s] = q.dz; W.sl_flag[s] = q.flag ? 1 : 0;
-    W.sl_moved[s] = 1;
-}
-AMC_DEV amc_particle rs_load_work(const rs_work &K, int w)
-{
-    amc_particle q;
-    q.x = K.x[w]; q.y = K.y[w]; q.z = K.z[w]; q.vx = K.vx[w]; q.vy = K.vy[w]; q.vz = K.vz[w];
-    q.d = K.d[w]; q.dx = K.dx[w]; q.dy = K.dy[w]; q.dz = K.dz[w]; q.flag = K.flag[w] != 0;
-    return q;
-}
-AMC_DEV void rs_store_work(const rs_work &K, int w, const amc_particle &q)
-{
-    K.x[w] = q.x; K.y[w] = q.y; K.z[w] = q.z; K.vx[w] = q.vx; K.vy[w] = q.vy; K.vz[w] = q.vz;
-    K.d[w] = q.d; K.dx[w] = q.dx; K.dy[w] = q.dy; K.dz[w] = q.dz; K.flag[w] = q.flag ? 1 : 0;
-    K.moved[w] = 1;
-}
-
-// history entry = one 32-byte record (x, y, z, slot | round << 32): one request to write it and one to read it (the
-// validation probes are bound by the number of memory requests a single CU can have in flight)
-AMC_DEV double4 rs_hist_make(double x, double y, double z, int slot, int gen)
-{
-    return make_double4(x, y, z, __longlong_as_double(((long long)gen << 32) | (unsigned int)slot));
-}
-AMC_DEV int rs_hist_slot(const double4 &r) { return (int)(unsigned int)(__double_as_longlong(r.w) & 0xffffffffLL); }
-AMC_DEV int rs_hist_gen(const double4 &r) { return (int)(__double_as_longlong(r.w) >> 32); }
-
-// one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
-// Returns true if the particles moved.
-AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
-                    int si, int phase, long long cell)
-{
-    const amc_resolve_ws &W = A.W;
-    auto emit = [&](int which, double tot, double px, double py, double pz) {
-        const int e = atomicAdd(&sh->nev, 1);
-        if (e < W.max_events) {
-            W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
-            W.ev_gen[e] = sh->cur_round; W.ev_slot[e] = si;
-            W.ev_val[4 * e + 0] = tot; W.ev_val[4 * e + 1] = px; W.ev_val[4 * e + 2] = py; W.ev_val[4 * e + 3] = pz;
-        } else {
-            sh->ovf = 1;
-        }
-    };
-    long long tq__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
-    const int fail__ = amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit);
-    if (A.dbg && threadIdx.x == 0) { if (p1.x == 1.2345e300) A.dbg[15] = 3; A.dbg[12] += wall_clock64() - tq__; }
-    if (fail__) {
-        atomicAdd(&sh->nfp, 1);     // the reference would raise FloatingPointError here (Pore:11,185)
-        return false;
-    }
-    atomicAdd(&W.sl_hits[si], 1);   // (no value needed back: the thread does not wait for the memory round trip)
-    const int h = atomicAdd(&sh->nhist, 2);
-    if (h + 1 < W.max_hist) {
-        W.hist[h] = rs_hist_make(p1.x, p1.y, p1.z, sj, sh->cur_round);
-        W.hist[h + 1] = rs_hist_make(p2.x, p2.y, p2.z, si, sh->cur_round);
-    } else {
-        sh->ovf = 1;
-    }
-    return true;
-}
-
-AMC_DEV int rs_pore_cell(const amc_params &P, double x, double y, double z, int gx, int gy, int gz)
-{
-    const int lx = amc_axis_cell(x, gx, P.nx, P.nx, P.dx, P.overlap_x);
-    if (lx < 0) return -1;
-    const int ly = amc_axis_cell(y, gy, P.ny, P.ny, P.dy, P.overlap_y);
-    if (ly < 0) return -1;
-    const int lz = amc_axis_cell(z, gz, P.nz / 2, 0, P.dz, P.overlap_z);
-    if (lz < 0) return -1;
-    return (lx * P.ny + ly) * (P.nz / 2) + lz;                                              // Pore:530 list order
-}
-
-// The (at most two) integers k with  k*d - ov < v < (k+1)*d  (Pore:527-529 with k = 2*layer+group-offset): the core
-// cell of v and, if v lies in the overlap strip, the next one.  INT_MIN marks "none".
-AMC_DEV void rs_axis_k(double v, double d, double inv_d, double ov, int &ka, int &kb)
-{
-    ka = kb = (int)0x80000000;
-    const double f = floor(v * inv_d);
-    if (!(f > -1.0e9 && f < 1.0e9)) return;
-    for (int dk = -1; dk <= 1; dk++) {
-        const int k = (int)f + dk;
-        const double lo = (double)k * d - ov, hi = (double)(k + 1) * d;
-        if (lo < v && v < hi) { if (ka == (int)0x80000000) ka = k; else kb = k; }
-    }
-}
-AMC_DEV void rs_pore_ks(const rs_args &A, const amc_particle &q, int *k)
-{
-    const amc_params &P = A.P;
-    rs_axis_k(q.x, P.dx, A.inv_dx, P.overlap_x, k[0], k[1]);
-    rs_axis_k(q.y, P.dy, A.inv_dy, P.overlap_y, k[2], k[3]);
-    rs_axis_k(q.z, P.dz, A.inv_dz, P.overlap_z, k[4], k[5]);
-}
-// layer of colour group `grp` along one axis from the cached k's (same rule as amc_axis_cell), -1 if none
-AMC_DEV int rs_layer_from_k(int ka, int kb, int grp, int nlayers, int offset)
-{
-    for (int t = 0; t < 2; t++) {
-        const int k = t ? kb : ka;
-        if (k == (int)0x80000000) continue;
-        const int twol = k - grp + offset;
-        if (twol < 0 || (twol & 1)) continue;
-        const int l = twol / 2;
-        if (l < nlayers) return l;
-    }
-    return -1;
-}
-AMC_DEV int rs_pore_cell_k(const amc_params &P, const int *k, int g)
-{
-    const int lx = rs_layer_from_k(k[0], k[1], g >> 2, P.nx, P.nx);
-    if (lx < 0) return -1;
-    const int ly = rs_layer_from_k(k[2], k[3], (g >> 1) & 1, P.ny, P.ny);
-    if (ly < 0) return -1;
-    const int lz = rs_layer_from_k(k[4], k[5], g & 1, P.nz / 2, 0);
-    if (lz < 0) return -1;
-    return (lx * P.ny + ly) * (P.nz / 2) + lz;                                              // Pore:530 list order
-}
-
-// smallest layer l >= from with  l*d - ov < v < (l+1)*d  for BOTH v1 and v2 (Cube:233), or -1
-AMC_DEV int rs_next_common(double v1, double v2, double d, double inv_d, double ov, int n, int from)
-{
-    const double vmin = v1 < v2 ? v1 : v2, vmax = v1 < v2 ? v2 : v1;
-    // the layer of vmax's core interval is the only one that can also hold a smaller coordinate; one below / above
-    // are tested as well so that the floor() guess never decides membership (the comparisons do)
-    const double f = floor(vmax * inv_d);
-    if (!(f > -2.0 && f < 1.0e9)) return -1;
-    int l0 = (int)f - 1;
-    if (l0 < from) l0 = from;
-    int l1 = (int)f + 1;
-    if (l1 > n - 1) l1 = n - 1;
-    for (int l = l0; l <= l1; l++) {
-        const double lo = l * d - ov, hi = (l + 1) * d;
-        if ((lo < vmin) && (vmax < hi)) return l;
-    }
-    return -1;
-}
-
-// ---- two-particle cluster: literal emulation with both particles in registers -----------------------------------------
-AMC_DEV amc_particle rs_load_cst(const amc_resolve_ws &W, int k, int which)
-{
-    const size_t m = (size_t)W.max_cand;
-    const double *t = W.cst + (size_t)(11 * which) * m + k;
-    amc_particle q;
-    q.x = t[0 * m]; q.y = t[1 * m]; q.z = t[2 * m]; q.vx = t[3 * m]; q.vy = t[4 * m]; q.vz = t[5 * m];
-    q.d = t[6 * m]; q.dx = t[7 * m]; q.dy = t[8 * m]; q.dz = t[9 * m]; q.flag = t[10 * m] != 0.0;
-    return q;
-}
-
-template <int GEOM>
-AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int pi, int sj, int si)
-{
-    const amc_params &P = A.P;
-    long long t0__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
-    amc_particle p1 = rs_load_cst(A.W, k, 0), p2 = rs_load_cst(A.W, k, 1);   // coalesced rows gathered by detect
-    if (A.dbg && threadIdx.x == 0) { if (p1.x + p2.x == 1.2345e300) A.dbg[15] = 1; const long long t1__ = wall_clock64(); A.dbg[13] += t1__ - t0__; t0__ = t1__; }
-    bool moved = false;
-    const double cr = P.collision_range;
-    if (GEOM == AMC_GEOM_CELL) {
-        if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr)) moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, 0);
-    } else if (GEOM == AMC_GEOM_CUBE) {
-        // Cube:231-238.  A coordinate lies in at most two overlapping layers, so the layers holding BOTH members are
-        // enumerated directly (rs_next_common) instead of walking all nx*ny*nz cells — lanes of a wave would each
-        // enter the nested loops at different iterations and the wave would execute the whole nest.
-        // The stale masks come out of the structure: the x test is made once when an x-layer starts, the y test
-        // once per (x,y)-layer, the z test per cell, each from the state at that moment (in_x_layer / in_y_layer /
-        // in_z_layer); none is re-evaluated after a hit inside the layer.
-        for (int lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
-             lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1))
-            for (int ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
-                 ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1))
-                for (int lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
-                     lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1))
-                    if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr))
-                        moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, ((long long)lx * P.ny + ly) * P.nz + lz);
-    } else {
-        // Pore:522-530.  Along one axis a coordinate belongs to at most two overlapping cells k (one of each parity);
-        // they are found once per particle (rs_axis_k) and re-derived only after a hit moved the particles, instead of
-        // dividing 48 times per pair.  Membership itself is decided by the reference's own comparisons.
-        int k1[6], k2[6];
-        rs_pore_ks(A, p1, k1);
-        rs_pore_ks(A, p2, k2);
-        // Lanes of a wave hold different pairs whose first shared colour group differs; with the hit inside the group
-        // loop the wave would run the (large) collision path once per group.  So each lane first SEARCHES its next
-        // group with a shared cell (cheap integer work), then all lanes resolve together, then the search resumes.
-        int g = 0;
-        bool ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);      // unchanged until a hit moves the pair
-        for (;;) {
-            int hit_g = -1, hit_c = -1;
-            if (ov)
-                for (; g < 8; g++) {                                                        // Pore:522-524
-                    const int c1 = rs_pore_cell_k(P, k1, g);
-                    if (c1 >= 0 && c1 == rs_pore_cell_k(P, k2, g)) { hit_g = g; hit_c = c1; break; }
-                }
-            if (hit_g < 0) break;
-            if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16 + hit_g, hit_c)) {
-                moved = true;
-                rs_pore_ks(A, p1, k1);
-                rs_pore_ks(A, p2, k2);
-                ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);
-            }
-            g = hit_g + 1;
-        }
-    }
-    if (moved) {
-        rs_store_slot(A.W, sj, p1);
-        rs_store_slot(A.W, si, p2);
-    }
-}
-
-// ---- generic cluster (3+ members): literal emulation on the working set [b,e) ----------------------
-AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int wj, int wi, int phase, long long cell)
-{
-    if (!amc_overlap(K.x[wj], K.y[wj], K.z[wj], K.x[wi], K.y[wi], K.z[wi], A.P.collision_range)) return;
-    amc_particle p1 = rs_load_work(K, wj), p2 = rs_load_work(K, wi);
-    const int pj = K.pidx[wj], pi = K.pidx[wi];
-    if (rs_hit(A, sh, p1, p2, pj, pi, K.slot[wj], K.slot[wi], phase, cell)) {
-        rs_store_work(K, wj, p1);
-        rs_store_work(K, wi, p2);
-    }
-}
-
-// smallest layer >= from that holds at least two members whose K.tmp has all bits of `need` set (0 = any member)
-AMC_DEV int rs_next_layer(const rs_work &K, int b, int e, const double *v, int need, double d, double inv_d, double ov,
-                          int n, int from)
-{
-    int best = -1;
-    for (int a = b + 1; a < e; a++) {
-        if ((K.tmp[a] & need) != need) continue;
-        for (int c = b; c < a; c++) {
-            if ((K.tmp[c] & need) != need) continue;
-            const int l = rs_next_common(v[a], v[c], d, inv_d, ov, n, from);
-            if (l >= 0 && (best < 0 || l < best)) best = l;
-        }
-    }
-    return best;
-}
-
-AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
-{
-    const amc_params &P = A.P;
-    if (P.geometry == AMC_GEOM_CELL) {
-        for (int a = b + 1; a < e; a++)                                                     // Pore:168-169
-            for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
-    } else if (P.geometry == AMC_GEOM_CUBE) {
-        // Cube:231-238 for a cluster: only layers that hold at least two members can do anything, so the next such
-        // layer is found from the member pairs (rs_next_common) instead of walking all nx*ny*nz cells.  K.tmp bit0/1/2 =
-        // the in_x / in_y / in_z masks, each taken when its layer starts (they stay stale inside it, as in the reference).
-        for (int lx = rs_next_layer(K, b, e, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
-             lx = rs_next_layer(K, b, e, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1)) {
-            const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;               // Cube:233
-            for (int a = b; a < e; a++) K.tmp[a] = ((xlo < K.x[a]) && (K.x[a] < xhi)) ? 1 : 0;
-            for (int ly = rs_next_layer(K, b, e, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
-                 ly = rs_next_layer(K, b, e, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1)) {
-                const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;           // Cube:235
-                for (int a = b; a < e; a++) {
-                    const int t = K.tmp[a] & 1;
-                    K.tmp[a] = t | ((t && (ylo < K.y[a]) && (K.y[a] < yhi)) ? 2 : 0);
-                }
-                for (int lz = rs_next_layer(K, b, e, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
-                     lz = rs_next_layer(K, b, e, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1)) {
-                    const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;       // Cube:237
-                    for (int a = b; a < e; a++) {
-                        const int t = K.tmp[a] & 3;
-                        K.tmp[a] = t | ((t == 3 && (zlo < K.z[a]) && (K.z[a] < zhi)) ? 4 : 0);
-                    }
-                    const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
-                    for (int a = b + 1; a < e; a++) {
-                        if (K.tmp[a] != 7) continue;
-                        for (int c = b; c < a; c++)
-                            if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
-                    }
-                }
-            }
-        }
-    } else {
-        for (int g = 0; g < 8; g++) {                                                        // Pore:522-524
-            const int gx = g >> 2, gy = (g >> 1) & 1, gz = g & 1;
-            int cnt = 0;
-            for (int a = b; a < e; a++) {
-                const int cell = rs_pore_cell(P, K.x[a], K.y[a], K.z[a], gx, gy, gz);
-                K.tmp[a] = cell;
-                cnt += cell >= 0;
-            }
-            if (cnt < 2) continue;
-            for (int a = b + 1; a < e; a++) {
-                const int ca = K.tmp[a];
-                if (ca < 0) continue;
-                for (int c = b; c < a; c++)
-                    if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
-            }
-        }
-    }
-}
-
-// bitonic sort of m (power of two) 64-bit keys; keys may live in LDS or global memory
-AMC_DEV void rs_bitonic(unsigned long long *keys, int m)
-{
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += RS_T) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = keys[i], b = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// slot bookkeeping: particle of the slot (global), cluster label = lowest slot id of the cluster and cluster size
-// (LDS when the sweep is small enough — the usual case — else the global work space)
-struct rs_slots {
-    int *p, *label, *size;
-    int cap;
-};
-
-// get (or create) the slot of particle p; creation is published by the barrier / kernel boundary that follows
-AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int cap, int p)
-{
-    const int old = atomicCAS(&W.slot_of[p], -1, -2);
-    if (old == -1) {
-        const int s = atomicAdd(&sh->nslots, 1);
-        if (s < cap) {
-            W.sl_p[s] = p;
-            W.slot_of[p] = s;
-        } else {
-            sh->ovf = 1;
-            W.slot_of[p] = -1;
-        }
-    }
-}
-
-// merge request found by validation: particles pa, pb must be in one cluster (slot ids are filled in next round)
-AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
-{
-    const int k = atomicAdd(&sh->nedges, 1);
-    if (k < W.max_edges) { W.edge_a[k] = pa; W.edge_b[k] = pb; } else sh->ovf = 1;
-    sh->dirty = 1;
-}
-
-
-// validation probe of history entry h: its position against every particle outside its cluster.  `cnt` are the
-// sweep counters (LDS inside a resolve kernel, W.ctl in the wide validate kernel), `label` the per-slot labels.
-// ---- the same emulation, run by a whole wave for ONE cluster -------------------------------------------------------------
-// A cluster is emulated by a single thread of control (the order of the pair tests is the reference's), and with one lane
-// doing it every load from the working set is a full LDS round trip and every instruction a wave-wide issue.  What does
-// not depend on the order — finding the next layer that holds two members (one lane per member PAIR, then a wave
-// minimum), taking the membership masks of all members, finding the members' pore cells — is spread over the lanes here;
-// only the pair tests of a cell stay on lane 0.  Control flow is uniform; the lanes meet at wave-level fences.
-#define RS_COOP_MAX 11      // members: 55 pairs fit the 64 lanes
-AMC_DEV void rs_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
-AMC_DEV int rs_wave_min_nonneg(int v)       // minimum over the lanes of the values >= 0, -1 if there is none
-{
-    unsigned int u = v < 0 ? 0xffffffffu : (unsigned int)v;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned int t = (unsigned int)__shfl_xor((int)u, o, 64);
-        u = t < u ? t : u;
-    }
-    return u == 0xffffffffu ? -1 : (int)u;
-}
-// lane's pair (a > c) of the cluster [b, e), or a = -1 for lanes beyond the number of pairs
-AMC_DEV void rs_lane_pair(int lane, int m, int &a, int &c)
-{
-    a = -1; c = -1;
-    int k = lane;
-    for (int i = 1; i < m; i++) {
-        if (k < i) { a = i; c = k; return; }
-        k -= i;
-    }
-}
-AMC_DEV int rs_next_layer_coop(const rs_work &K, int b, int pa, int pc, const double *v, int need, double d, double inv_d,
-                               double ov, int n, int from)
-{
-    int l = -1;
-    if (pa >= 0 && (K.tmp[b + pa] & need) == need && (K.tmp[b + pc] & need) == need)
-        l = rs_next_common(v[b + pa], v[b + pc], d, inv_d, ov, n, from);
-    return rs_wave_min_nonneg(l);
-}
-
-AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
-{
-    const amc_params &P = A.P;
-    const int lane = threadIdx.x & 63, m = e - b;
-    const int w = b + lane;                 // my member (lanes < m)
-    int pa, pc;
-    rs_lane_pair(lane, m, pa, pc);
-    if (P.geometry == AMC_GEOM_CELL) {
-        if (lane == 0)
-            for (int a = b + 1; a < e; a++)                                                 // Pore:168-169
-                for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
-        rs_wave_sync();
-    } else if (P.geometry == AMC_GEOM_CUBE) {
-        // Cube:231-238, structure as in rs_emulate_generic (stale in_x / in_y / in_z masks in K.tmp bit 0/1/2)
-        for (int lx = rs_next_layer_coop(K, b, pa, pc, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
-             lx = rs_next_layer_coop(K, b, pa, pc, K.x, 0, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1)) {
-            const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;               // Cube:233
-            if (lane < m) K.tmp[w] = ((xlo < K.x[w]) && (K.x[w] < xhi)) ? 1 : 0;
-            rs_wave_sync();
-            for (int ly = rs_next_layer_coop(K, b, pa, pc, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
-                 ly = rs_next_layer_coop(K, b, pa, pc, K.y, 1, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1)) {
-                const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;           // Cube:235
-                if (lane < m) {
-                    const int t = K.tmp[w] & 1;
-                    K.tmp[w] = t | ((t && (ylo < K.y[w]) && (K.y[w] < yhi)) ? 2 : 0);
-                }
-                rs_wave_sync();
-                for (int lz = rs_next_layer_coop(K, b, pa, pc, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
-                     lz = rs_next_layer_coop(K, b, pa, pc, K.z, 3, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1)) {
-                    const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;       // Cube:237
-                    if (lane < m) {
-                        const int t = K.tmp[w] & 3;
-                        K.tmp[w] = t | ((t == 3 && (zlo < K.z[w]) && (K.z[w] < zhi)) ? 4 : 0);
-                    }
-                    rs_wave_sync();
-                    if (lane == 0) {
-                        const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
-                        for (int a = b + 1; a < e; a++) {
-                            if (K.tmp[a] != 7) continue;
-                            for (int c = b; c < a; c++)
-                                if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
-                        }
-                    }
-                    rs_wave_sync();
-                }
-            }
-        }
-    } else {
-        for (int g = 0; g < 8; g++) {                                                        // Pore:522-524
-            const int gx = g >> 2, gy = (g >> 1) & 1, gz = g & 1;
-            int cell = -1;
-            if (lane < m) {                                                                  // membership at gather time
-                cell = rs_pore_cell(P, K.x[w], K.y[w], K.z[w], gx, gy, gz);
-                K.tmp[w] = cell;
-            }
-            const int cnt = __popcll(__ballot(cell >= 0));
-            rs_wave_sync();
-            if (cnt < 2) continue;
-            if (lane == 0)
-                for (int a = b + 1; a < e; a++) {
-                    const int ca = K.tmp[a];
-                    if (ca < 0) continue;
-                    for (int c = b; c < a; c++)
-                        if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
-                }
-            rs_wave_sync();
-        }
-    }
-}
-
-#define RS_PF 4     // lists whose first element rs_probe prefetches
-AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const int *label, int ns, int cap, int h,
-                      double cr2i)
-{
-    const amc_resolve_ws &W = A.W;
-    const double4 me = W.hist[h];
-    const int sme = rs_hist_slot(me);
-    const int pme = W.sl_p[sme];
-    const int lme = label[sme];
-    const double x = me.x, y = me.y, z = me.z;
-    // only the cells overlapped by the collision_range box around the new position can hold a partner (2 to 3 on
-    // average): fetch their list heads and overlay heads first, then the entries
-    int c_lo[4], c_hi[4], lh[8], ovh[8];
-    const int ncell = amc_grid_box_ranges(G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
-    // list heads and overlay heads of every overlapped cell first (one memory round trip), then the entries
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        lh[2 * k] = lh[2 * k + 1] = -1; ovh[2 * k] = ovh[2 * k + 1] = -1;
-        if (k < ncell) {
-            lh[2 * k] = amc_list_head(A.B, c_lo[k]); ovh[2 * k] = W.ov_head[c_lo[k]];
-            if (c_hi[k] != c_lo[k]) { lh[2 * k + 1] = amc_list_head(A.B, c_hi[k]); ovh[2 * k + 1] = W.ov_head[c_hi[k]]; }
-        }
-    }
-    const int nx_me = W.ov_next[h], nx_pa = W.ov_next[h ^ 1];       // to step over my own / my partner's entry without a round trip
-    // The probe is a chain of dependent memory round trips, so the FIRST element of every list (grid and overlay) is
-    // fetched before any is examined; longer lists (rare at ~0.25 particles per cell) continue one element at a time.
-    double4 r0[RS_PF], o0[RS_PF];
-    int on0[RS_PF];
-#pragma unroll
-    for (int k = 0; k < RS_PF; k++) {
-        if (lh[k] >= 0) r0[k] = A.B.rec[lh[k]];
-        // history entries are allocated in pairs (the two particles of one hit): h ^ 1 is my partner's entry — same
-        // cluster by construction, and for an isolated pair the only other entry nearby: skipped before any load
-        while (ovh[k] >= 0 && (ovh[k] | 1) == (h | 1)) ovh[k] = (ovh[k] == h) ? nx_me : nx_pa;
-        if (ovh[k] >= 0) {
-            const int h2 = ovh[k];
-            o0[k] = W.hist[h2]; on0[k] = W.ov_next[h2];
-        }
-    }
-    auto grid_entry = [&](int idx, const double4 &r) {
-        if (idx == pme) return;
-        const double ax = r.x - x, ay = r.y - y, az = r.z - z;
-        if (ax * ax + ay * ay + az * az < cr2i) {
-            const int so = W.slot_of[idx];
-            if (so >= 0 && so < ns && label[so] == lme) return;
-            if (so < 0) rs_claim_slot(W, cnt, cap, idx);
-            rs_add_edge(W, cnt, pme, idx);
-        }
-    };
-    auto overlay_entry = [&](const double4 &o) {
-        const int s2 = rs_hist_slot(o);
-        if (rs_hist_gen(o) != W.sl_gen[s2]) return;       // position of an emulation that was redone since
-        if (label[s2] == lme) return;
-        const double ax = o.x - x, ay = o.y - y, az = o.z - z;
-        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
-    };
-    // pre-sweep positions of the particles binned into those cells
-#pragma unroll
-    for (int k = 0; k < RS_PF; k++)
-        if (lh[k] >= 0) {
-            grid_entry(lh[k], r0[k]);
-            for (int q = amc_rec_next(r0[k]); q >= 0;) {
-                const double4 r = A.B.rec[q];
-                grid_entry(q, r);
-                q = amc_rec_next(r);
-            }
-        }
-    for (int k = RS_PF; k < 2 * ncell; k++)
-        for (int q = lh[k]; q >= 0;) {
-            const double4 r = A.B.rec[q];
-            grid_entry(q, r);
-            q = amc_rec_next(r);
-        }
-    // new positions of other clusters' members (overlay lists of the same cells)
-#pragma unroll
-    for (int k = 0; k < RS_PF; k++)
-        if (ovh[k] >= 0) {
-            overlay_entry(o0[k]);
-            for (int h2 = on0[k]; h2 >= 0;) {
-                if ((h2 | 1) == (h | 1)) { h2 = (h2 == h) ? nx_me : nx_pa; continue; }
-                const int nx = W.ov_next[h2];
-                overlay_entry(W.hist[h2]);
-                h2 = nx;
-            }
-        }
-    for (int k = RS_PF; k < 2 * ncell; k++)
-        for (int h2 = ovh[k]; h2 >= 0; h2 = W.ov_next[h2]) {
-            if ((h2 | 1) == (h | 1)) continue;
-            overlay_entry(W.hist[h2]);
-        }
-}
-
-AMC_DEV int rs_hist_cell(const rs_args &A, const amc_grid &G, int h)
-{
-    int cx, cy, cz;
-    const double4 r = A.W.hist[h];
-    amc_grid_coords(G, r.x, r.y, r.z, cx, cy, cz);
-    return amc_grid_cell(G, cx, cy, cz, nullptr);
-}
+#include "amc_resolve_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
     do {                                                                                   \
@@ -1108,30 +500,6 @@ __global__ __launch_bounds__(256) void k_gather_cst(rs_args A)
     }
 }
 
-// exchange table [11][n]: rows of the particles this rank owns, zero bits elsewhere (the all-reduce is an integer SUM of the int64 view: exact)
-__global__ __launch_bounds__(256) void k_pack_rows(amc_state S, const int *list, int n, long long lo, long long hi, double *table)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
-    const int p = list[u];
-    const bool own = p >= lo && p < hi;
-    const double v[11] = {S.x[p], S.y[p], S.z[p], S.vx[p], S.vy[p], S.vz[p], S.d[p], S.dx[p], S.dy[p], S.dz[p],
-                          S.flag[p] ? 1.0 : 0.0};
-    for (int e = 0; e < 11; e++) table[(size_t)e * n + u] = own ? v[e] : 0.0;
-}
-__global__ __launch_bounds__(256) void k_unpack_rows(amc_state S, const int *list, int n, long long lo, long long hi, const double *table)
-{
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
-    const int p = list[u];
-    if (p >= lo && p < hi) return;          // the owner's copy is authoritative
-    S.x[p] = table[(size_t)0 * n + u]; S.y[p] = table[(size_t)1 * n + u]; S.z[p] = table[(size_t)2 * n + u];
-    S.vx[p] = table[(size_t)3 * n + u]; S.vy[p] = table[(size_t)4 * n + u]; S.vz[p] = table[(size_t)5 * n + u];
-    S.d[p] = table[(size_t)6 * n + u]; S.dx[p] = table[(size_t)7 * n + u]; S.dy[p] = table[(size_t)8 * n + u];
-    S.dz[p] = table[(size_t)9 * n + u];
-    S.flag[p] = table[(size_t)10 * n + u] != 0.0;
-}
-
 template <int GEOM>
 static void rs_launch_all(amc_ctx *c, const rs_args &A)
 {
@@ -1230,54 +598,5 @@ hipError_t amc_launch_commit(amc_ctx *c)
     amc_prof_begin(c, AMC_K_RESOLVE);
     hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
     amc_prof_end(c);
-    return hipGetLastError();
-}
-// ---- packed position exchange (one all-gather per step): send = [3][m], recv = [world][3][m] ---------------------------
-__global__ __launch_bounds__(256) void k_pos_pack(const double *__restrict__ x, const double *__restrict__ y,
-                                                  const double *__restrict__ z, long long lo, long long hi, long long m,
-                                                  double *__restrict__ send)
-{
-    const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= m) return;
-    const bool in = lo + u < hi;
-    send[u] = in ? x[lo + u] : 0.0;
-    send[m + u] = in ? y[lo + u] : 0.0;
-    send[2 * m + u] = in ? z[lo + u] : 0.0;
-}
-__global__ __launch_bounds__(256) void k_pos_unpack(double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
-                                                    long long n, int world, int rank, long long m,
-                                                    const double *__restrict__ recv)
-{
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)world * m) return;
-    const int r = (int)(idx / m);
-    const long long u = idx % m;
-    if (r == rank) return;                                  // my own shard is already in place
-    const long long base = n / world, rem = n % world;
-    const long long lo = r * base + (r < rem ? r : rem), cnt = base + (r < rem ? 1 : 0);
-    if (u >= cnt) return;
-    const double *blk = recv + (size_t)r * 3 * (size_t)m;
-    x[lo + u] = blk[u];
-    y[lo + u] = blk[m + u];
-    z[lo + u] = blk[2 * m + u];
-}
-hipError_t amc_launch_pos_pack(amc_ctx *c, int world, int rank, int unpack)
-{
-    const long long m = c->pos_m;
-    if (m <= 0) return hipSuccess;
-    if (!unpack)
-        hipLaunchKernelGGL(k_pos_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z,
-                           (long long)c->lo, (long long)c->hi, m, c->pos_send);
-    else
-        hipLaunchKernelGGL(k_pos_unpack, dim3((unsigned)(((long long)world * m + 255) / 256)), dim3(256), 0, c->stream, c->S.x,
-                           c->S.y, c->S.z, (long long)c->n, world, rank, m, c->pos_recv);
-    return hipGetLastError();
-}
-
-hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack)
-{
-    if (n <= 0) return hipSuccess;
-    if (unpack) hipLaunchKernelGGL(k_unpack_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, d_list, n, c->lo, c->hi, table);
-    else hipLaunchKernelGGL(k_pack_rows, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, d_list, n, c->lo, c->hi, table);
     return hipGetLastError();
 }
