@@ -44,6 +44,7 @@ SIGNATURES = {
     "amc_temp_end": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_temp_cases_device": (C.c_int, [_ctx, C.POINTER(AmcTempRng)]),
     "amc_temp_device_results": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_temp_device_sums": (C.c_int, [_ctx, _dp, C.POINTER(C.c_int32)]),
     "amc_temp_device_draws": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),

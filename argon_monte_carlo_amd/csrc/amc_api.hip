@@ -947,6 +947,41 @@ int amc_temp_device_results(amc_ctx *c, int case_id, int32_t *idx, double *dpz, 
     return AMC_OK;
 }
 
+int amc_temp_device_sums(amc_ctx *c, double *sums, int32_t *had)
+{
+    if (!c || !sums || !had || !c->TD.idx) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    int rc = temp_dev_fetch(c);
+    if (rc) return rc;
+    amc_temp_dev_ws &D = c->TD;
+    sums[0] = sums[1] = sums[2] = 0.0;
+    had[0] = had[1] = had[2] = 0;
+    std::vector<int> perm;
+    for (int s = 0; s < 7; s++) {
+        const int case_id = 3 + s;
+        const size_t k = (size_t)std::max(D.h_count[s], 0);
+        if (!k) continue;
+        perm.resize(k);
+        for (size_t u = 0; u < k; u++) perm[u] = (int)u;
+        std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });
+        double m_case = 0.0, e_case = 0.0;
+        bool any = false;
+        for (size_t u = 0; u < k; u++) {
+            const int r = perm[u];
+            if (!D.h_ok[s][r]) continue;
+            m_case = m_case + D.h_dpz[s][r];
+            e_case = e_case + D.h_dE[s][r];
+            any = true;
+        }
+        sums[0] = sums[0] + m_case;
+        had[0] |= any ? 1 : 0;
+        const bool cold = (case_id == 3 || case_id == 7 || case_id == 9), hot = (case_id == 4 || case_id == 6 || case_id == 8);
+        if (cold) { sums[1] = sums[1] + e_case; had[1] |= any ? 1 : 0; }
+        if (hot) { sums[2] = sums[2] + e_case; had[2] |= any ? 1 : 0; }
+    }
+    return AMC_OK;
+}
+
 int amc_temp_device_draws(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
                           double *surface_energy, size_t cap, size_t *n)
 {
@@ -986,8 +1021,11 @@ int amc_temp_end(amc_ctx *c, amc_step_stats *out)
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "amc_temp_end needs AMC_GEOM_PORE_ENERGISED");
-    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));        // Temp:804
-    int rc = enqueue_sweep(c);                                      // Temp:813-842
+    // the bounds pass before the sweep sees every particle at its final pre-sweep position: it builds the detection
+    // grid's lists as well (like the fused streaming pass of the specular geometries)
+    const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
+    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0, fuse));  // Temp:804
+    int rc = enqueue_sweep(c, fuse);                                // Temp:813-842
     if (rc) return rc;
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));        // Temp:844
     c->out.step++;

@@ -36,6 +36,60 @@ __device__ inline bool temp_mask(const amc_params &P, int case_id, double x, dou
     }
 }
 
+// contact of a hit of case `case_id`: flight time since contact, contact point, inward unit normal (Temp:349-375 for the
+// planes, Temp:430-474 for the cylinders); ok = 0 when the cylinder solve has no real root (Temp:472-474)
+struct temp_contact {
+    double t, cx, cy, cz, n0, n1, n2;
+    unsigned char ok;
+};
+__device__ inline temp_contact temp_solve(const amc_params &P, int case_id, double x, double y, double z, double vx,
+                                          double vy, double vz)
+{
+    temp_contact c;
+    c.ok = 1; c.t = 0; c.cx = 0; c.cy = 0; c.cz = 0; c.n0 = 0; c.n1 = 0; c.n2 = 0;
+    if (case_id == 3 || case_id == 4 || case_id == 6 || case_id == 7) {
+        const double zp = case_id == 3 ? P.t_z3_cold : case_id == 4 ? P.t_z3_hot : case_id == 6 ? P.t_zgap_lo : P.t_zgap_hi;
+        c.t = (z - zp) / vz;                                                                 // Temp:353
+        c.cx = x - vx * c.t; c.cy = y - vy * c.t; c.cz = zp;                                 // Temp:372
+        c.n2 = (case_id == 3 || case_id == 6) ? 1.0 : -1.0;                                  // Temp:709,714,730,736
+    } else {
+        const double Rc = case_id == 5 ? P.R_g_c : P.R_p_c;
+        const double a = (-vx) * (-vx) + (-vy) * (-vy);                                      // Temp:436
+        const double b = 2 * (x * (-vx) + y * (-vy));
+        const double cc = x * x + y * y - Rc * Rc;
+        const double disc2 = b * b - 4 * a * cc;
+        if (a == 0.0 || disc2 < 0.0 || disc2 != disc2) {
+            c.ok = 0;                                                                        // Temp:472-474
+        } else {
+            const double sq = sqrt(disc2);
+            const double t1 = (-b + sq) / (2 * a), t2 = (-b - sq) / (2 * a);
+            c.t = (t1 < t2) ? t1 : t2;                                                       // Temp:439
+            c.cx = x - vx * c.t; c.cy = y - vy * c.t; c.cz = z - vz * c.t;                   // Temp:440
+            c.n0 = -(c.cx / Rc); c.n1 = -(c.cy / Rc); c.n2 = -(0.0 / Rc);                    // Temp:442-444 (negated)
+        }
+    }
+    return c;
+}
+
+// energy accommodation and new velocity of a hit (Temp:377-388); returns the particle's speed before the hit
+__device__ inline double temp_accommodate(const amc_params &P, int case_id, double vx, double vy, double vz, double Es,
+                                          double d0, double d1, double d2, double &wvx, double &wvy, double &wvz,
+                                          double &dpz, double &dE)
+{
+    const double m = P.argon_mass;
+    const double alpha = (case_id == 5) ? P.alpha_gap : P.alpha_coated;
+    const double v_magnitude = sqrt(vx * vx + vy * vy + vz * vz);                            // Temp:377
+    const double old_pz = m * vz;                                                            // Temp:378
+    const double E = 0.5 * m * (v_magnitude * v_magnitude);                                  // Temp:128-129,379
+    const double diff = Es - E;                                                              // Temp:380
+    const double Enew = E + diff * alpha;                                                    // Temp:381
+    const double mag = sqrt(Enew * 2 / m);                                                   // Temp:383
+    dE = Enew - E;                                                                           // Temp:384
+    wvx = d0 * mag; wvy = d1 * mag; wvz = d2 * mag;                                          // Temp:386
+    dpz = m * wvz - old_pz;                                                                  // Temp:387-388
+    return v_magnitude;
+}
+
 __global__ __launch_bounds__(256) void k_temp_hits(amc_state S, amc_params P, int case_id, long long lo, long long hi,
                                                    temp_records R, amc_dev_counters *cnt)
 {
@@ -45,34 +99,11 @@ __global__ __launch_bounds__(256) void k_temp_hits(amc_state S, amc_params P, in
     if (!temp_mask(P, case_id, x, y, z, S.px[p], S.py[p], S.pz[p])) return;
     const int k = atomicAdd(R.count, 1);
     if (k >= R.cap) { atomicOr(&cnt->flags, 4ULL); return; }
-    const double vx = S.vx[p], vy = S.vy[p], vz = S.vz[p];
     R.idx[k] = (int)p;
-    unsigned char ok = 1;
-    double t = 0, cx = 0, cy = 0, cz = 0, n0 = 0, n1 = 0, n2 = 0;
-    if (case_id == 3 || case_id == 4 || case_id == 6 || case_id == 7) {
-        const double zp = case_id == 3 ? P.t_z3_cold : case_id == 4 ? P.t_z3_hot : case_id == 6 ? P.t_zgap_lo : P.t_zgap_hi;
-        t = (z - zp) / vz;                                                                   // Temp:353
-        cx = x - vx * t; cy = y - vy * t; cz = zp;                                           // Temp:372
-        n2 = (case_id == 3 || case_id == 6) ? 1.0 : -1.0;                                    // Temp:709,714,730,736
-    } else {
-        const double Rc = case_id == 5 ? P.R_g_c : P.R_p_c;
-        const double a = (-vx) * (-vx) + (-vy) * (-vy);                                      // Temp:436
-        const double b = 2 * (x * (-vx) + y * (-vy));
-        const double c = x * x + y * y - Rc * Rc;
-        const double disc2 = b * b - 4 * a * c;
-        if (a == 0.0 || disc2 < 0.0 || disc2 != disc2) {
-            ok = 0;                                                                          // Temp:472-474
-        } else {
-            const double sq = sqrt(disc2);
-            const double t1 = (-b + sq) / (2 * a), t2 = (-b - sq) / (2 * a);
-            t = (t1 < t2) ? t1 : t2;                                                         // Temp:439
-            cx = x - vx * t; cy = y - vy * t; cz = z - vz * t;                               // Temp:440
-            n0 = -(cx / Rc); n1 = -(cy / Rc); n2 = -(0.0 / Rc);                              // Temp:442-444 (negated)
-        }
-    }
-    R.t[k] = t; R.ok[k] = ok;
-    R.contact[3 * k] = cx; R.contact[3 * k + 1] = cy; R.contact[3 * k + 2] = cz;
-    R.normal[3 * k] = n0; R.normal[3 * k + 1] = n1; R.normal[3 * k + 2] = n2;
+    const temp_contact c = temp_solve(P, case_id, x, y, z, S.vx[p], S.vy[p], S.vz[p]);
+    R.t[k] = c.t; R.ok[k] = c.ok;
+    R.contact[3 * k] = c.cx; R.contact[3 * k + 1] = c.cy; R.contact[3 * k + 2] = c.cz;
+    R.normal[3 * k] = c.n0; R.normal[3 * k + 1] = c.n1; R.normal[3 * k + 2] = c.n2;
 }
 
 __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, amc_out O, int case_id, int n,
@@ -86,19 +117,11 @@ __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, a
     dpz[k] = 0; dE[k] = 0;
     if (!R.ok[k]) { atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, 1ULL); atomicAdd(&O.banks[amc_bank_id()].n_wall, 1ULL); return; }
     const int p = R.idx[k];
-    const double m = P.argon_mass;
-    const double alpha = (case_id == 5) ? P.alpha_gap : P.alpha_coated;
     const double t = R.t[k];
     const double vx = S.vx[p], vy = S.vy[p], vz = S.vz[p];
-    const double v_magnitude = sqrt(vx * vx + vy * vy + vz * vz);                            // Temp:377
-    const double old_pz = m * vz;                                                            // Temp:378
-    const double E = 0.5 * m * (v_magnitude * v_magnitude);                                  // Temp:128-129,379
-    const double diff = Es[k] - E;                                                           // Temp:380
-    const double Enew = E + diff * alpha;                                                    // Temp:381
-    const double mag = sqrt(Enew * 2 / m);                                                   // Temp:383
-    dE[k] = Enew - E;                                                                        // Temp:384
-    const double wvx = dir[3 * k] * mag, wvy = dir[3 * k + 1] * mag, wvz = dir[3 * k + 2] * mag;   // Temp:386
-    dpz[k] = m * wvz - old_pz;                                                               // Temp:387-388
+    double wvx, wvy, wvz;
+    const double v_magnitude = temp_accommodate(P, case_id, vx, vy, vz, Es[k], dir[3 * k], dir[3 * k + 1], dir[3 * k + 2], wvx,
+                                                wvy, wvz, dpz[k], dE[k]);
     if (S.flag[p])                                                                           // Temp:391-395
         amc_emit(O, case_id + 1, 0, p, -1, 0, fabs(S.d[p] - fabs(v_magnitude * t)), fabs(S.dx[p] - fabs(vx * t)),
                  fabs(S.dy[p] - fabs(vy * t)), fabs(S.dz[p] - fabs(vz * t)));
@@ -172,20 +195,16 @@ __device__ inline double temp_gap_energy(const amc_temp_rng &g, double z)
     return 9 * t_gap * g.n_alumina * g.boltzman * (r * r * r) * q;                   // Temp:152
 }
 
-__global__ __launch_bounds__(256) void k_temp_sample(amc_params P, amc_temp_rng g, int case_id, unsigned int step,
-                                                     temp_records R, double *__restrict__ dir, double *__restrict__ Es)
+// re-emission direction (Temp:119-141 recipe on Philox numbers) and surface energy of one hit
+__device__ inline void temp_draw(const amc_params &P, const amc_temp_rng &g, int case_id, unsigned int step, int particle,
+                                 double n0, double n1, double n2, double contact_z, double &fx, double &fy, double &fz,
+                                 double &Es)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= min(*R.count, R.cap)) return;
-    dir[3 * k] = dir[3 * k + 1] = dir[3 * k + 2] = 0.0;
-    Es[k] = 0.0;
-    if (!R.ok[k]) return;
-    const double n0 = R.normal[3 * k], n1 = R.normal[3 * k + 1], n2 = R.normal[3 * k + 2];
     const double cos85 = 0.087155742747658166;      // cos(85 deg), Temp:136
     const double pi = 3.14159265358979323846;
-    double fx = 0, fy = 0, fz = 0;
+    fx = fy = fz = 0;
     for (unsigned int attempt = 0; attempt < 4096u; attempt++) {                     // Temp:133-141 (acceptance ~91 %)
-        unsigned int c[4] = {(unsigned int)R.idx[k], step, ((unsigned int)case_id << 16) | attempt, 0x414d4331u};
+        unsigned int c[4] = {(unsigned int)particle, step, ((unsigned int)case_id << 16) | attempt, 0x414d4331u};
         philox4x32_10(c, g.seed);
         const double u1 = (double)((((unsigned long long)c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0);
         const double u2 = (double)((((unsigned long long)c[2] << 32) | c[3]) >> 12) * (1.0 / 4503599627370496.0);
@@ -201,9 +220,88 @@ __global__ __launch_bounds__(256) void k_temp_sample(amc_params P, amc_temp_rng 
         if (d < cos85) { fx = -fx; fy = -fy; fz = -fz; }                             // Temp:138-139
         break;
     }
+    Es = (case_id == 5) ? temp_gap_energy(g, contact_z)
+                        : ((case_id == 3 || case_id == 7 || case_id == 9) ? P.E_cold : P.E_hot);
+}
+
+__global__ __launch_bounds__(256) void k_temp_sample(amc_params P, amc_temp_rng g, int case_id, unsigned int step,
+                                                     temp_records R, double *__restrict__ dir, double *__restrict__ Es)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= min(*R.count, R.cap)) return;
+    dir[3 * k] = dir[3 * k + 1] = dir[3 * k + 2] = 0.0;
+    Es[k] = 0.0;
+    if (!R.ok[k]) return;
+    double fx, fy, fz, e;
+    temp_draw(P, g, case_id, step, R.idx[k], R.normal[3 * k], R.normal[3 * k + 1], R.normal[3 * k + 2], R.contact[3 * k + 2],
+              fx, fy, fz, e);
     dir[3 * k] = fx; dir[3 * k + 1] = fy; dir[3 * k + 2] = fz;
-    Es[k] = (case_id == 5) ? temp_gap_energy(g, R.contact[3 * k + 2])
-                           : ((case_id == 3 || case_id == 7 || case_id == 9) ? P.E_cold : P.E_hot);
+    Es[k] = e;
+}
+
+// All seven energised cases of a step in ONE pass (device-RNG mode): every case reads and writes only the particle
+// itself and the masks are evaluated in case order, each after the previous handler ran (Temp:705-758) — which per
+// particle is a sequential evaluation, so with the random numbers available on the device the 7 x (hits, sample,
+// apply) kernels collapse into this one.  The per-hit records (one segment per case) are still written: the host
+// sums their z-momentum / energy changes in the reference's order, tests read the draws.
+struct temp_dev_segments {
+    int *idx, *count;
+    double *t, *contact, *normal, *dir, *Es, *dpz, *dE;
+    unsigned char *ok;
+    int cap;
+};
+__global__ __launch_bounds__(256) void k_temp_all(amc_state S, amc_params P, amc_out O, amc_temp_rng g, unsigned int step,
+                                                  long long lo, long long hi, temp_dev_segments D, amc_dev_counters *cnt)
+{
+    const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hi) return;
+    double x = S.x[p], y = S.y[p], z = S.z[p];
+    const double px = S.px[p], py = S.py[p], pz = S.pz[p];
+    bool any = false;
+    for (int case_id = 3; case_id <= 9; case_id++)
+        any |= temp_mask(P, case_id, x, y, z, px, py, pz);
+    if (!any) return;                                   // (a hit moves the particle: the masks are re-evaluated below)
+    double vx = S.vx[p], vy = S.vy[p], vz = S.vz[p];
+    double d = S.d[p], dx = S.dx[p], dy = S.dy[p], dz = S.dz[p];
+    bool flag = S.flag[p] != 0;
+    int nwall = 0, nerr = 0;
+    for (int case_id = 3; case_id <= 9; case_id++) {
+        if (!temp_mask(P, case_id, x, y, z, px, py, pz)) continue;
+        const int s = case_id - 3;
+        const int k = atomicAdd(&D.count[s], 1);
+        const bool rec = k < D.cap;
+        if (!rec) atomicOr(&cnt->flags, 4ULL);
+        const size_t o = (size_t)s * (size_t)D.cap + (size_t)(rec ? k : 0);
+        const temp_contact c = temp_solve(P, case_id, x, y, z, vx, vy, vz);
+        double fx = 0, fy = 0, fz = 0, es = 0, dpz = 0, dE = 0;
+        nwall++;                                                                             // Temp:411,482,552
+        if (!c.ok) {
+            nerr++;                                                                          // Temp:472-474
+        } else {
+            temp_draw(P, g, case_id, step, (int)p, c.n0, c.n1, c.n2, c.cz, fx, fy, fz, es);
+            double wvx, wvy, wvz;
+            const double v_magnitude = temp_accommodate(P, case_id, vx, vy, vz, es, fx, fy, fz, wvx, wvy, wvz, dpz, dE);
+            if (flag)                                                                        // Temp:391-395
+                amc_emit(O, case_id + 1, 0, (int)p, -1, 0, fabs(d - fabs(v_magnitude * c.t)), fabs(dx - fabs(vx * c.t)),
+                         fabs(dy - fabs(vy * c.t)), fabs(dz - fabs(vz * c.t)));
+            else
+                flag = true;
+            d = 0; dx = 0; dy = 0; dz = 0;                                                   // Temp:398-401
+            x = c.cx; y = c.cy; z = c.cz;                                                    // Temp:402
+            vx = wvx; vy = wvy; vz = wvz;                                                    // Temp:403
+        }
+        if (rec) {
+            D.idx[o] = (int)p; D.t[o] = c.t; D.ok[o] = c.ok;
+            D.contact[3 * o] = c.cx; D.contact[3 * o + 1] = c.cy; D.contact[3 * o + 2] = c.cz;
+            D.normal[3 * o] = c.n0; D.normal[3 * o + 1] = c.n1; D.normal[3 * o + 2] = c.n2;
+            D.dir[3 * o] = fx; D.dir[3 * o + 1] = fy; D.dir[3 * o + 2] = fz;
+            D.Es[o] = es; D.dpz[o] = dpz; D.dE[o] = dE;
+        }
+    }
+    S.x[p] = x; S.y[p] = y; S.z[p] = z; S.vx[p] = vx; S.vy[p] = vy; S.vz[p] = vz;
+    S.d[p] = d; S.dx[p] = dx; S.dy[p] = dy; S.dz[p] = dz; S.flag[p] = flag ? 1 : 0;
+    if (nwall) atomicAdd(&O.banks[amc_bank_id()].n_wall, (unsigned long long)nwall);
+    if (nerr) atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, (unsigned long long)nerr);
 }
 
 hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
@@ -212,6 +310,16 @@ hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
     amc_temp_dev_ws &D = c->TD;
     hipError_t e = hipMemsetAsync(D.count, 0, sizeof(int) * 7, c->stream);
     if (e != hipSuccess || cnt <= 0) return e;
+    static int unfused = -1;
+    if (unfused < 0) unfused = getenv("AMC_TEMP_UNFUSED") ? 1 : 0;      // cross-check path: one hits/sample/apply triple per case
+    if (!unfused) {
+        temp_dev_segments G;
+        G.idx = D.idx; G.count = D.count; G.t = D.t; G.contact = D.contact; G.normal = D.normal; G.dir = D.dir;
+        G.Es = D.Es; G.dpz = D.dpz; G.dE = D.dE; G.ok = D.ok; G.cap = D.cap;
+        hipLaunchKernelGGL(k_temp_all, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, c->out, *cfg,
+                           (unsigned int)c->out.step, c->lo, c->hi, G, c->d_cnt);
+        return hipGetLastError();
+    }
     const unsigned rec_blocks = (unsigned)((D.cap + 255) / 256);
     for (int s = 0; s < 7; s++) {
         const int case_id = 3 + s;

@@ -318,12 +318,13 @@ class EnergisedEngine(Engine):
 
     def temp_timestep_device(self, dt, cfg):
         """temp_timestep with the random draws on the device: same return tuple, no per-case host round trip."""
-        from .energised import CASES, sum_device_cases
         self.temp_begin(dt)
         self.temp_cases_device(cfg)
         st = self.temp_end()
-        res = {case: self.device_results(case)[1:] for case in CASES}
-        return (st,) + sum_device_cases(res)
+        sums = (C.c_double * 3)()
+        had = (C.c_int32 * 3)()
+        self._ck(self.lib.amc_temp_device_sums(self._ctx, sums, had))
+        return (st, sums[0], sums[1], sums[2], bool(had[0]), bool(had[1]), bool(had[2]))
 
     def temp_timestep(self, dt, sampler, energies):
         """One iteration of Temperature_Pore_MC.py's loop (Temp:662-853)."""

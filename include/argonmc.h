@@ -241,6 +241,10 @@ typedef struct amc_temp_rng {
 } amc_temp_rng;
 int amc_temp_cases_device(amc_ctx *ctx, const amc_temp_rng *cfg);
 int amc_temp_device_results(amc_ctx *ctx, int case_id, int32_t *idx, double *dpz, double *dE, uint8_t *ok, size_t cap, size_t *n);
+/* the step's sums of those per-hit changes, formed like Temp:385-389 / 705-758 do (left to right in ascending particle
+ * index inside a case, cases in order): sums[0] = z-momentum, [1] = energy to the cold walls, [2] = to the hot walls;
+ * had[k] != 0 if any hit contributed to sums[k] */
+int amc_temp_device_sums(amc_ctx *ctx, double *sums /*[3]*/, int32_t *had /*[3]*/);
 int amc_temp_device_draws(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
                           double *surface_energy, size_t cap, size_t *n);
 

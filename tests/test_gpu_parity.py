@@ -589,6 +589,9 @@ def test_device_rng_energised_walls_match_oracle_on_the_same_draws(O):
     n_hits = n_gap = 0
     for s in range(3):
         st, mom, cold, hot, hm, hc, hh = eng.temp_timestep_device(dt, cfg)
+        # the library's per-step sums == the reference-order accumulation of the per-hit results
+        from argon_monte_carlo_amd.energised import sum_device_cases
+        assert (mom, cold, hot, hm, hc, hh) == sum_device_cases({case: eng.device_results(case)[1:] for case in CASES})
         orc._temp_wall_count = 0
         orc._temp_errs = 0
         orc.drift(dt, True)
