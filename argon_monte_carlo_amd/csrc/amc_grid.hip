@@ -88,16 +88,19 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
+    bool pending = false;
     if (p < n) {
         const double4 me = B.rec[p];
         auto found_pair = [&](int q) {
+            if (!pending) {                        // first pair of this lane: pushed at the end, together with the gather
+                pending = true; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
+                return;
+            }
             const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt);
-            if (my_k >= 0 && kk >= 0) {
+            if (kk >= 0) {
                 const int hi = (int)p > q ? (int)p : q, lo = (int)p > q ? q : (int)p;
                 for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
                     cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? hi : lo, e % 11);
-            } else if (kk >= 0) {
-                my_k = kk; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
             }
         };
         // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
@@ -146,8 +149,21 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
                 }
         }
     }
-    const unsigned long long found = __ballot(my_k >= 0);
-    if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);
+    unsigned long long found = __ballot(pending);
+    if (found) {
+        // the state of the first found pair (most waves have at most one) is requested BEFORE the push, so that its
+        // loads and the counter's atomic are in flight together: one memory round trip less at the tail of the kernel
+        const int lane = threadIdx.x & 63;
+        const int src0 = __ffsll((long long)found) - 1;
+        const int pi0 = __shfl(my_i, src0, 64), pj0 = __shfl(my_j, src0, 64);
+        double v0 = 0.0;
+        if (lane < 22) v0 = amc_state_elem(S, lane / 11 ? pi0 : pj0, lane % 11);
+        if (pending) my_k = amc_push_candidate(my_i, my_j, cand_i, cand_j, max_cand, cnt);
+        const int k0 = __shfl(my_k, src0, 64);
+        if (k0 >= 0 && lane < 22) cst[(size_t)lane * (size_t)max_cand + k0] = v0;
+        found &= found - 1;
+        if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);
+    }
 }
 
 // ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
