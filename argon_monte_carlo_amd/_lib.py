@@ -59,6 +59,8 @@ SIGNATURES = {
     "amc_mg_candidates": (C.c_int, [_ctx, _i32p, _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_mg_pack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
     "amc_mg_unpack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
+    "amc_mg_exchange_begin": (C.c_int, [_ctx, _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_mg_exchange_end": (C.c_int, [_ctx]),
     "amc_mg_resolve_round": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_mg_positions_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "amc_mg_pack_positions": (C.c_int, [_ctx, C.c_int]),

@@ -225,7 +225,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->mg_ncand = 0;
-    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0;
+    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0; c->mg_list_n = 0;
     c->pos_send = c->pos_recv = nullptr; c->pos_world = 0; c->pos_m = 0;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
@@ -1188,6 +1188,39 @@ int amc_mg_unpack_state(amc_ctx *c, const int32_t *particles, size_t n)
     int rc = mg_upload_list(c, particles, n);
     if (rc) return rc;
     AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 1));
+    return AMC_OK;
+}
+
+int amc_mg_exchange_begin(amc_ctx *c, const int32_t *particles, size_t n, size_t *n_rows)
+{
+    if (!c || !n_rows) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    std::vector<int32_t> list;
+    if (!particles) {
+        const size_t k = std::min<size_t>((size_t)std::max(c->mg_ncand, 0), (size_t)c->W.max_cand);
+        list.resize(2 * k);
+        if (k) {
+            int rc = amc_mg_candidates(c, list.data(), list.data() + k, k, &n);       // staged by amc_mg_detect: no device access
+            if (rc) return rc;
+        }
+        std::sort(list.begin(), list.end());
+        list.erase(std::unique(list.begin(), list.end()), list.end());                // canonical order: ascending particle index
+        particles = list.data();
+        n = list.size();
+    }
+    int rc = mg_upload_list(c, particles, n);
+    if (rc) return rc;
+    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 0));
+    c->mg_list_n = n;
+    *n_rows = n;
+    return AMC_OK;
+}
+
+int amc_mg_exchange_end(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)c->mg_list_n, (double *)c->xchg_send, 1));
     return AMC_OK;
 }
 

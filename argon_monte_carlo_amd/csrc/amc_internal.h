@@ -143,6 +143,7 @@ struct amc_ctx {
     int *d_host_ncand;             // its device address
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     int mg_ncand;                  // candidate count read back by the last amc_mg_detect
+    size_t mg_list_n;              // rows of the exchange begun by amc_mg_exchange_begin
     // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
     char *h_pin;
     size_t h_pin_bytes;

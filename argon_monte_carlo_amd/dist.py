@@ -152,11 +152,18 @@ class ShardedSimulation:
     # ---- one step -------------------------------------------------------------------------------------------------------
     def _exchange_state(self, particles):
         """Rows of `particles` (ascending, identical on every rank) from their owners to everybody."""
+        e = self.engine
+        if hasattr(e, "mg_exchange_begin"):          # list built / uploaded once inside the library
+            n = e.mg_exchange_begin(particles)
+            if n:
+                self.comm.allreduce_bits(e.exchange_tensor(n))
+                e.mg_exchange_end()
+            return
         if len(particles) == 0:
             return
-        self.engine.mg_pack(particles)
-        self.comm.allreduce_bits(self.engine.exchange_tensor(len(particles)))
-        self.engine.mg_unpack(particles)
+        e.mg_pack(particles)
+        self.comm.allreduce_bits(e.exchange_tensor(len(particles)))
+        e.mg_unpack(particles)
 
     def timestep(self, dt, reduce_stats=True, want_stats=True):
         self.engine.mg_local(dt)
@@ -177,9 +184,12 @@ class ShardedSimulation:
         ncand = e.mg_detect()
         rounds = 0
         if ncand:
-            ci, cj = e.mg_candidates(ncand)
-            known = np.unique(np.concatenate([ci, cj]))              # canonical order: ascending particle index
-            self._exchange_state(known)
+            if hasattr(e, "mg_exchange_begin"):
+                self._exchange_state(None)                           # endpoints of the candidates, canonical order
+            else:
+                ci, cj = e.mg_candidates(ncand)
+                known = np.unique(np.concatenate([ci, cj]))          # canonical order: ascending particle index
+                self._exchange_state(known)
             dirty, new = e.mg_resolve_round(True)
             rounds = 1
             while dirty:

@@ -233,6 +233,19 @@ class ShardEngine(Engine):
         p = np.ascontiguousarray(particles, dtype=np.int32)
         self._ck(self.lib.amc_mg_pack_state(self._ctx, self._i32(p), len(p)))
 
+    def mg_exchange_begin(self, particles=None):
+        """Pack this rank's rows of the exchange list (None: the endpoints of the detected candidates); returns the rows."""
+        n = C.c_size_t(0)
+        if particles is None:
+            self._ck(self.lib.amc_mg_exchange_begin(self._ctx, None, 0, C.byref(n)))
+        else:
+            p = np.ascontiguousarray(particles, dtype=np.int32)
+            self._ck(self.lib.amc_mg_exchange_begin(self._ctx, self._i32(p), len(p), C.byref(n)))
+        return n.value
+
+    def mg_exchange_end(self):
+        self._ck(self.lib.amc_mg_exchange_end(self._ctx))
+
     def mg_unpack(self, particles):
         p = np.ascontiguousarray(particles, dtype=np.int32)
         self._ck(self.lib.amc_mg_unpack_state(self._ctx, self._i32(p), len(p)))

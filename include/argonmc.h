@@ -287,6 +287,11 @@ int amc_mg_unpack_positions(amc_ctx *ctx, int world, int rank);
 int amc_mg_detect(amc_ctx *ctx, int64_t *n_candidates);
 int amc_mg_candidates(amc_ctx *ctx, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n);
 int amc_mg_pack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
+/* the same exchange in two calls around the all-reduce, with the list built and uploaded once: `particles` == NULL takes
+ * the sorted set of endpoints of the candidates amc_mg_detect found (identical on every rank), otherwise the given
+ * ascending list (new cluster members); *n_rows = rows to reduce.  amc_mg_exchange_end unpacks the reduced table. */
+int amc_mg_exchange_begin(amc_ctx *ctx, const int32_t *particles, size_t n, size_t *n_rows);
+int amc_mg_exchange_end(amc_ctx *ctx);
 int amc_mg_unpack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
 /* first != 0: start the sweep (claim slots, round 1); else continue with the next round.  *dirty = clusters merged
  * (another round is needed); new_members receives the particles pulled in by validation (ascending). */
