@@ -45,11 +45,9 @@ for s in range(steps):
     timed("pos_unpack", e.mg_unpack_positions, sim.world, sim.rank)
     ncand = timed("mg_detect", e.mg_detect)
     if ncand:
-        ci, cj = timed("mg_candidates", e.mg_candidates, ncand)
-        known = timed("unique", lambda: np.unique(np.concatenate([ci, cj])))
-        timed("x_pack", e.mg_pack, known)
-        timed("x_allreduce", sim.comm.allreduce_bits, e.exchange_tensor(len(known)))
-        timed("x_unpack", e.mg_unpack, known)
+        nrows = timed("x_begin", e.mg_exchange_begin, None)
+        timed("x_allreduce", sim.comm.allreduce_bits, e.exchange_tensor(nrows))
+        timed("x_end", e.mg_exchange_end)
         dirty, new = timed("round1", e.mg_resolve_round, True)
         while dirty:
             timed("exchange2", sim._exchange_state, new)
