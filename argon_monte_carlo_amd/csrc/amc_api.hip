@@ -153,7 +153,7 @@ const char *amc_last_error(const amc_ctx *ctx) { return ctx ? ctx->err.c_str() :
 const char *amc_kernel_name(int k)
 {
     static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan",     "bin_scatter", "detect",  "resolve",
-                                             "bounds",      "validate",  "resolve_more", "commit",      "other10", "other11"};
+                                             "bounds",      "validate",  "resolve_more", "commit",      "pairs_wide", "other11"};
     return (k >= 0 && k < AMC_K_COUNT) ? names[k] : "?";
 }
 
@@ -172,7 +172,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
-                    c->W.ev_gen, c->W.ev_slot};
+                    c->W.ev_gen, c->W.ev_slot, c->W.wctl, c->W.deg, c->W.cand_done};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -225,7 +225,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->mg_ncand = 0;
-    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0; c->mg_list_n = 0;
+    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0; c->mg_list_n = 0; c->plan_split = false;
     c->pos_send = c->pos_recv = nullptr; c->pos_world = 0; c->pos_m = 0;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
@@ -279,6 +279,13 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.cst, (size_t)22 * W.max_cand));
         CK(dalloc(&W.ctl, 64));
         CK(hipMemsetAsync(W.ctl, 0, sizeof(int) * 64, c->stream));
+        CK(dalloc(&W.wctl, 64));
+        CK(hipMemsetAsync(W.wctl, 0, sizeof(int) * 64, c->stream));
+        { amc_resolve_ctl z; memset(&z, 0, sizeof z); z.cur_round = 1; CK(hipMemcpyAsync(W.wctl, &z, sizeof z, hipMemcpyHostToDevice, c->stream)); CK(hipStreamSynchronize(c->stream)); }
+        CK(dalloc(&W.deg, n));
+        CK(hipMemsetAsync(W.deg, 0, sizeof(unsigned int) * std::max<size_t>(n, 1), c->stream));
+        CK(dalloc(&W.cand_done, (size_t)W.max_cand));
+        c->sweep_epoch = 0;
         CK(dalloc(&W.slot_of, n));
         CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));
         const size_t ms = (size_t)W.max_slots;

@@ -38,12 +38,34 @@ __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x,
 // A candidate is stored as (i, j) with i > j plus a copy of both particles' state in a SoA table (cst[e][k], e = 0..10
 // particle j, 11..21 particle i): the single-workgroup resolve kernel then reads coalesced rows instead of issuing
 // 22 scattered loads per pair from one CU.  Returns the candidate's slot (or -1 on overflow).
-AMC_DEV int amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt)
+// number of candidates that touch particle p in this sweep, saturating at 3, tagged with the sweep's epoch so that the
+// table is never cleared: the wide pair kernel (amc_resolve.hip) takes the pairs whose endpoints both have degree one
+struct amc_degrees {
+    unsigned int *deg;
+    unsigned int epoch;
+};
+AMC_DEV void amc_degree_inc(const amc_degrees &D, int p)
+{
+    if (!D.deg) return;
+    unsigned int old = D.deg[p];
+    for (;;) {
+        const unsigned int c = (old >> 2) == D.epoch ? (old & 3u) : 0u;
+        const unsigned int nw = (D.epoch << 2) | (c < 3u ? c + 1u : 3u);
+        const unsigned int seen = atomicCAS(&D.deg[p], old, nw);
+        if (seen == old) break;
+        old = seen;
+    }
+}
+
+AMC_DEV int amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
+                               const amc_degrees &D)
 {
     const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
     if (k < (unsigned)max_cand) {
         cand_i[k] = a > b ? a : b;
         cand_j[k] = a > b ? b : a;
+        amc_degree_inc(D, a);
+        amc_degree_inc(D, b);
         return (int)k;
     }
     atomicOr(&cnt->flags, 1ULL);
@@ -84,7 +106,7 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
 __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                                                      amc_state S, double *cst)
+                                                      amc_state S, double *cst, amc_degrees D)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
@@ -96,7 +118,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
                 pending = true; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
                 return;
             }
-            const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt);
+            const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt, D);
             if (kk >= 0) {
                 const int hi = (int)p > q ? (int)p : q, lo = (int)p > q ? q : (int)p;
                 for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
@@ -158,7 +180,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
         const int pi0 = __shfl(my_i, src0, 64), pj0 = __shfl(my_j, src0, 64);
         double v0 = 0.0;
         if (lane < 22) v0 = amc_state_elem(S, lane / 11 ? pi0 : pj0, lane % 11);
-        if (pending) my_k = amc_push_candidate(my_i, my_j, cand_i, cand_j, max_cand, cnt);
+        if (pending) my_k = amc_push_candidate(my_i, my_j, cand_i, cand_j, max_cand, cnt, D);
         const int k0 = __shfl(my_k, src0, 64);
         if (k0 >= 0 && lane < 22) cst[(size_t)lane * (size_t)max_cand + k0] = v0;
         found &= found - 1;
@@ -171,7 +193,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ z, int n, int ntiles, double cr2i,
                                                           int *cand_i, int *cand_j, int max_cand,
-                                                          amc_dev_counters *cnt, amc_state S, double *cst)
+                                                          amc_dev_counters *cnt, amc_state S, double *cst, amc_degrees D)
 {
     // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -196,7 +218,7 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
         const double d2 = ex * ex + ey * ey + ez * ez;
         if (d2 < cr2i) {
-            const int kk = amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt);
+            const int kk = amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt, D);
             if (kk >= 0)
                 for (int e = 0; e < 22; e++)
                     cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? i : (j0 + k), e % 11);
@@ -222,16 +244,23 @@ hipError_t amc_launch_detect(amc_ctx *c)
     const long long n = c->n;
     if (n <= 0) return hipSuccess;
     const double cr2i = c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE;
+    amc_degrees D;
+    c->sweep_epoch = (c->sweep_epoch + 1u) & 0x3fffffffu;
+    if (c->sweep_epoch == 0u) c->sweep_epoch = 1u;      // (0 is the value of the zero-initialised table)
+    // launch plan of this sweep from the candidate count of the most recent sweep the host has seen (a word the resolve
+    // kernel writes into host-mapped memory; it may lag by a step): only the large plan uses the degrees
+    c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= AMC_PLAN_SMALL);
+    D.deg = c->plan_split ? c->W.deg : nullptr; D.epoch = c->sweep_epoch;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);
         const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
         if (nblocks > 0)
             hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
-                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst);
+                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
     } else {
         hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
-                           c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst);
+                           c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
     }
     amc_prof_end(c);
     return hipGetLastError();

@@ -76,6 +76,9 @@ struct amc_resolve_ws {
     double *ev_val;           // [max_events][4]
     int max_events;
     int *ctl;                 // rs_shared in global memory: hand-over between the resolve kernels
+    int *wctl;                // rs_shared of the wide pair kernel (counters it advanced before the ordered workgroup starts)
+    unsigned int *deg;        // [n] candidates touching the particle in the current sweep: (sweep epoch << 2) | min(count, 3)
+    uint8_t *cand_done;       // [max_cand] pair already emulated by the wide pair kernel
     double *cst;              // [22][max_cand] state of both particles of every candidate, gathered by detect
 };
 
@@ -144,6 +147,8 @@ struct amc_ctx {
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     int mg_ncand;                  // candidate count read back by the last amc_mg_detect
     size_t mg_list_n;              // rows of the exchange begun by amc_mg_exchange_begin
+    unsigned int sweep_epoch;      // tag of the degree counts of the current sweep (advanced by every detect launch)
+    bool plan_split;               // launch plan of the current sweep, fixed when its detect kernel is launched
     // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
     char *h_pin;
     size_t h_pin_bytes;
@@ -167,6 +172,7 @@ void amc_prof_end(amc_ctx *c);
 void amc_prof_collect(amc_ctx *c);
 
 // stage bits of the streaming kernel
+#define AMC_PLAN_SMALL 640      // candidate pairs up to which the single resolve kernel does the whole sweep (RS_SMALL)
 #define AMC_ST_DRIFT 1
 #define AMC_ST_WALLS 2
 #define AMC_ST_BOUNDS 4

@@ -38,7 +38,7 @@
 
 #define RS_NS 6144             // slot labels / sizes / dirty flags kept in LDS (54 KB)
 #define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
-#define RS_SMALL 640           // candidate pairs up to which resolve_A does everything itself
+#define RS_SMALL AMC_PLAN_SMALL // candidate pairs up to which resolve_A does everything itself
 
 // MODE 0: first round only (claim, label, emulate), validation + commit are the wide kernels that follow
 // MODE 1: continuation: if the wide validation found merges, run the remaining rounds (validation in-kernel)
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     __shared__ rs_shared sh;
+    __shared__ int wide_ns;             // slots made by the wide pair kernel in this sweep, -1 if it did not run
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
     __shared__ double pool_d[10][RS_POOL];
     __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL], pool_slot[RS_POOL];
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     amc_dev_counters *cnt = A.O.cnt;
     rs_shared *ctl = (rs_shared *)W.ctl;
     int ncand;
+    if (threadIdx.x == 0) wide_ns = -1;
     if (MODE == 1) {
         if (tid == 0) sh = *ctl;
         __syncthreads();
@@ -70,9 +72,20 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         if (ncand > W.max_cand) ncand = W.max_cand;
         __syncthreads();
         if (tid == 0) {
-            sh.nslots = 0; sh.nedges = 0; sh.nhist = 0; sh.nev = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
-            sh.nfp = 0; sh.ovf = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
-            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0; sh.nslots0 = 0;
+            // what the wide pair kernel did before this one (slots, history, events of the isolated pairs); zero if it
+            // did not run.  Its control block is re-armed for the next sweep.
+            sh.nslots = 0; sh.nhist = 0; sh.nev = 0; sh.nfp = 0; sh.ovf = 0;
+            if (A.wide_plan) {
+                rs_shared *wc = (rs_shared *)W.wctl;
+                sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
+                sh.nhist = wc->nhist; sh.nev = wc->nev; sh.nfp = wc->nfp; sh.ovf = wc->ovf;
+                wide_ns = wc->active ? sh.nslots : -1;             // (>= 0: the wide kernel ran, W.cand_done is valid)
+                wc->nslots = 0; wc->nhist = 0; wc->nev = 0; wc->nfp = 0; wc->ovf = 0; wc->active = 0; wc->cur_round = 1;
+            }
+            sh.nslots0 = 0;
+            sh.nedges = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
+            sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
+            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0;
             sh.lazy_ns = 0;         // the streaming pass before this sweep consumed the previous sweep's deferred results
             cnt->cand_count = 0;
             if (A.host_ncand) *A.host_ncand = ncand;
@@ -102,12 +115,15 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     if (MODE != 1) {
         // ---- slots for the candidate endpoints; candidates become slot pairs -------------------------------------------
+        const bool wide = wide_ns >= 0;
         for (int k = tid; k < ncand; k += RS_T) {
+            if (wide && W.cand_done[k]) continue;           // isolated pair: slots, state and history exist already
             rs_claim_slot(W, &sh, V.cap, W.cand_i[k]);
             rs_claim_slot(W, &sh, V.cap, W.cand_j[k]);
         }
         __syncthreads();
         for (int k = tid; k < ncand; k += RS_T) {
+            if (wide && W.cand_done[k]) continue;
             W.cand_si[k] = W.slot_of[W.cand_i[k]];
             W.cand_sj[k] = W.slot_of[W.cand_j[k]];
         }
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         const int edges_new = edges_done;
         edges_done = nedges;
-        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = sh.nhist < W.max_hist ? sh.nhist : W.max_hist; }
+        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = (rounds == 1) ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
         __syncthreads();
         // ---- connected components by label propagation (label = lowest slot id of the cluster) -------------------------
         for (;;) {
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         __syncthreads();
         for (int s = tid; s < ns; s += RS_T)
-            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; W.sl_hits[s] = 0; }
+            if (vdirty[V.label[s]] && !(rounds == 1 && s < wide_ns)) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; W.sl_hits[s] = 0; }
         __syncthreads();
         RS_STAMP(1);
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
@@ -242,6 +258,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const int si = W.cand_si[k], sj = W.cand_sj[k];
                 if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
                 if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
+                if (rounds == 1 && wide_ns >= 0 && W.cand_done[k]) continue;       // emulated by the wide pair kernel
                 rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
             }
         }
@@ -399,6 +416,47 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     }
 }
 
+// ---- isolated pairs, wide -----------------------------------------------------------------------------------------------------
+// Everything in k_resolve costs time in proportion to the number of candidates (~38 ns each on its single CU).  Nine
+// candidates in ten are isolated pairs — both particles appear in no other candidate (degree one, counted by the detect
+// kernel) — and need none of its machinery: no claim race, no labels, no ordering against other pairs.  This kernel
+// gives them their slots (two per pair from one counter, allocated per wave) and emulates them exactly like the
+// workgroup would (rs_emulate_pair); the workgroup then starts from the counters left in W.wctl and handles only the
+// entangled remainder.  Validation treats both kinds alike (the pair's history entries are probed by k_validate).
+template <int GEOM>
+__global__ __launch_bounds__(256) void k_pairs_wide(rs_args A)
+{
+    const amc_resolve_ws &W = A.W;
+    rs_shared *wc = (rs_shared *)W.wctl;
+    int ncand = (int)A.O.cnt->cand_count;
+    if (ncand > W.max_cand) ncand = W.max_cand;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wc->active = 1;
+    const unsigned int one = (A.sweep_epoch << 2) | 1u;
+    const int lane = threadIdx.x & 63, stride = gridDim.x * blockDim.x;
+    for (int k0 = blockIdx.x * blockDim.x + (threadIdx.x - lane); k0 < ncand; k0 += stride) {     // wave-uniform trip count
+        const int k = k0 + lane;
+        const bool valid = k < ncand;
+        int pi = 0, pj = 0;
+        bool iso = false;
+        if (valid) {
+            pi = W.cand_i[k]; pj = W.cand_j[k];
+            iso = W.deg[pi] == one && W.deg[pj] == one;
+        }
+        const int base = rs_count_add(&wc->nslots, iso ? 2 : 0);
+        if (iso && base + 1 >= W.max_slots) { wc->ovf = 1; iso = false; }
+        if (valid) W.cand_done[k] = iso ? 1 : 0;
+        if (!iso) continue;
+        const int sj = base, si = base + 1;
+        W.slot_of[pj] = sj; W.slot_of[pi] = si;
+        W.sl_p[sj] = pj; W.sl_p[si] = pi;
+        W.cand_sj[k] = sj; W.cand_si[k] = si;
+        W.sl_moved[sj] = 0; W.sl_moved[si] = 0;
+        W.sl_gen[sj] = 1; W.sl_gen[si] = 1;
+        atomicAnd(&W.sl_hits[sj], 0); atomicAnd(&W.sl_hits[si], 0);      // (atomics, like the increments that follow)
+        rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si);
+    }
+}
+
 // ---- wide kernels around the single-workgroup resolve (grid mode) ---------------------------------------------------------
 // validation of the first round: one thread per history entry, spread over the chip (the probes are scattered reads,
 // and one CU sustains only ~85 outstanding misses per microsecond)
@@ -510,13 +568,20 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     // launch plan from the candidate count of the most recent sweep the host has seen (a word the kernel writes into
     // host-mapped memory; no synchronisation, it may lag by a step): small sweeps need only this one kernel.  Either
     // plan is correct for any count — a wrong guess only costs time.
-    if (c->h_host_ncand && *c->h_host_ncand <= RS_SMALL) {
+    if (!c->plan_split) {
         rs_args B = A;
         B.force_mono = 1;
         hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, B);
         return;
     }
-    hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    rs_args Aw = A;
+    Aw.wide_plan = 1;
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_PAIRS_WIDE);
+    hipLaunchKernelGGL((k_pairs_wide<GEOM>), dim3(64), dim3(256), 0, c->stream, Aw);
+    amc_prof_end(c);
+    amc_prof_begin(c, AMC_K_RESOLVE);
+    hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, Aw);
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_VALIDATE);
     hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
@@ -539,6 +604,8 @@ static rs_args rs_make_args(amc_ctx *c)
     A.host_ncand = c->d_host_ncand;
     A.defer_commit = 0;
     A.apply_only = 0;
+    A.sweep_epoch = c->sweep_epoch;
+    A.wide_plan = 0;
     A.count_pp = c->mg_count_pp ? 1 : 0;
     A.lo = c->lo; A.hi = c->hi;
     A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;

@@ -29,6 +29,8 @@ struct rs_args {
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
     double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
     long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
+    unsigned int sweep_epoch; // tag of W.deg entries that belong to this sweep (0: degrees were not collected)
+    int wide_plan;            // k_pairs_wide ran before this kernel: start from the counters it left in W.wctl
 };
 
 // counters of one sweep; lives in LDS while a resolve kernel runs and in W.ctl (global) between the kernels
@@ -84,6 +86,21 @@ AMC_DEV double4 rs_hist_make(double x, double y, double z, int slot, int gen)
 AMC_DEV int rs_hist_slot(const double4 &r) { return (int)(unsigned int)(__double_as_longlong(r.w) & 0xffffffffLL); }
 AMC_DEV int rs_hist_gen(const double4 &r) { return (int)(__double_as_longlong(r.w) >> 32); }
 
+// counter += n for every lane that is here right now, with ONE atomic for the whole group (n in 0..2); returns the
+// lane's own first index.  The counters live in LDS for the ordered workgroup and in global memory for the wide pair
+// kernel, where a same-address atomic per hit would be a serial chain of ~12 ns each.
+AMC_DEV int rs_count_add(int *counter, int n)
+{
+    if (__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)counter)) return atomicAdd(counter, n);   // LDS: cheap as it is
+    const unsigned long long act = __ballot(1), b1 = __ballot(n >= 1), b2 = __ballot(n >= 2);
+    const int lane = (int)__lane_id(), leader = __ffsll((long long)act) - 1;
+    const unsigned long long lt = (1ULL << lane) - 1ULL;
+    const int before = __popcll(b1 & lt) + __popcll(b2 & lt), total = __popcll(b1) + __popcll(b2);
+    int base = 0;
+    if (lane == leader && total) base = atomicAdd(counter, total);
+    return __shfl(base, leader, 64) + before;
+}
+
 // one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
 // Returns true if the particles moved.
 AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
@@ -91,7 +108,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
 {
     const amc_resolve_ws &W = A.W;
     auto emit = [&](int which, double tot, double px, double py, double pz) {
-        const int e = atomicAdd(&sh->nev, 1);
+        const int e = rs_count_add(&sh->nev, 1);
         if (e < W.max_events) {
             W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
             W.ev_gen[e] = sh->cur_round; W.ev_slot[e] = si;
@@ -108,7 +125,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
         return false;
     }
     atomicAdd(&W.sl_hits[si], 1);   // (no value needed back: the thread does not wait for the memory round trip)
-    const int h = atomicAdd(&sh->nhist, 2);
+    const int h = rs_count_add(&sh->nhist, 2);
     if (h + 1 < W.max_hist) {
         W.hist[h] = rs_hist_make(p1.x, p1.y, p1.z, sj, sh->cur_round);
         W.hist[h + 1] = rs_hist_make(p2.x, p2.y, p2.z, si, sh->cur_round);

@@ -312,6 +312,7 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 #define AMC_K_VALIDATE 7         /* k_validate (wide first-round validation)                                    */
 #define AMC_K_RESOLVE_MORE 8     /* k_resolve continuation (further rounds after a merge)                       */
 #define AMC_K_COMMIT 9           /* k_commit                                                                    */
+#define AMC_K_PAIRS_WIDE 10      /* k_pairs_wide: isolated pairs of a large sweep, before the ordered workgroup   */
 #define AMC_K_COUNT 12
 int amc_profile(amc_ctx *ctx, int enable);
 int amc_kernel_times(amc_ctx *ctx, double *total_ms /*[AMC_K_COUNT]*/, int64_t *launches /*[AMC_K_COUNT]*/);
