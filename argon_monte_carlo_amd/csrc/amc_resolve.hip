@@ -133,16 +133,25 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     int rounds = sh.rounds;
     int edges_done = sh.edges_done;     // edges [0, edges_done) already hold slot ids
+    int ns_lab = 0;                     // slots that carry a label of the previous round
+    if (MODE == 1) {
+        // continuation: the labels of the round(s) before are in global memory (written at the hand-over)
+        ns_lab = sh.nslots0 < V.cap ? sh.nslots0 : V.cap;
+        if (V.label != W.sl_label)
+            for (int s = tid; s < ns_lab; s += RS_T) V.label[s] = W.sl_label[s];
+        __syncthreads();
+    }
     for (;;) {
         rounds++;
         const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
         const int nedges = sh.nedges < W.max_edges ? sh.nedges : W.max_edges;
         __syncthreads();
         // ---- per-round reset; new merge edges: particle ids -> slot ids -------------------------------------------------
+        const bool first = (rounds == 1);
         for (int s = tid; s < ns; s += RS_T) {
-            V.label[s] = s;
-            V.size[s] = 0;
-            vdirty[s] = (rounds == 1);          // round 1 emulates everything; later rounds only what the new edges touch
+            if (first || s >= ns_lab) V.label[s] = s;       // later rounds keep the previous round's labels
+            V.size[s] = first ? 0 : s;                      // (later rounds: parent map of the cluster merges, see below)
+            vdirty[s] = first;                              // round 1 emulates everything; later rounds only what the new edges touch
         }
         for (int k = edges_done + tid; k < nedges; k += RS_T) {
             W.edge_a[k] = W.slot_of[W.edge_a[k]];
@@ -150,21 +159,43 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         const int edges_new = edges_done;
         edges_done = nedges;
-        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = (rounds == 1) ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
+        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
         __syncthreads();
-        // ---- connected components by label propagation (label = lowest slot id of the cluster) -------------------------
-        for (;;) {
-            int changed = 0;
-            for (int k = tid; k < ncand + nedges; k += RS_T) {
-                const int sa = k < ncand ? W.cand_si[k] : W.edge_a[k - ncand];
-                const int sb = k < ncand ? W.cand_sj[k] : W.edge_b[k - ncand];
-                if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
-                const int la = V.label[sa], lb = V.label[sb];
-                if (la < lb) { atomicMin(&V.label[sb], la); changed = 1; }
-                else if (lb < la) { atomicMin(&V.label[sa], lb); changed = 1; }
+        if (first) {
+            // ---- connected components by label propagation (label = lowest slot id of the cluster); the pairs the wide
+            // kernel emulated are isolated by construction: their label is known without propagation ----------------------
+            const bool wide1 = wide_ns >= 0;
+            if (wide1)
+                for (int k = tid; k < ncand; k += RS_T)
+                    if (W.cand_done[k]) V.label[W.cand_si[k]] = W.cand_sj[k];              // (sj = si - 1)
+            for (;;) {
+                int changed = 0;
+                for (int k = tid; k < ncand; k += RS_T) {
+                    if (wide1 && W.cand_done[k]) continue;
+                    const int sa = W.cand_si[k], sb = W.cand_sj[k];
+                    if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
+                    const int la = V.label[sa], lb = V.label[sb];
+                    if (la < lb) { atomicMin(&V.label[sb], la); changed = 1; }
+                    else if (lb < la) { atomicMin(&V.label[sa], lb); changed = 1; }
+                }
+                if (!__syncthreads_or(changed)) break;
             }
-            if (!__syncthreads_or(changed)) break;
+        } else {
+            // ---- later rounds: the clusters of the previous round merge along the NEW edges only — a union over label
+            // values (parent map in V.size, roots = minimum label) and one relabelling pass, instead of propagating
+            // over every candidate again ----------------------------------------------------------------------------------------
+            for (int k = edges_new + tid; k < nedges; k += RS_T) {
+                const int sa = W.edge_a[k], sb = W.edge_b[k];
+                if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
+                rs_union(V.size, V.label[sa], V.label[sb]);
+            }
+            __syncthreads();
+            for (int s = tid; s < ns; s += RS_T) V.label[s] = rs_find(V.size, V.label[s]);
+            __syncthreads();
+            for (int s = tid; s < ns; s += RS_T) V.size[s] = 0;
+            __syncthreads();
         }
+        ns_lab = ns;
         // ---- cluster sizes, accumulated on the label slot ------------------------------------------------------------------
         for (int s = tid; s < ns; s += RS_T) atomicAdd(&V.size[V.label[s]], 1);
         // clusters touched by the merge edges of the previous validation are re-emulated; everything else keeps its

@@ -407,6 +407,25 @@ AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int cap, int 
     }
 }
 
+// union of two clusters in a parent map over label values (M[l] = l for a root; roots are the minimum label of their set)
+AMC_DEV int rs_find(const int *M, int x)
+{
+    while (M[x] != x) x = M[x];
+    return x;
+}
+AMC_DEV void rs_union(int *M, int a, int b)
+{
+    for (;;) {
+        a = rs_find(M, a);
+        b = rs_find(M, b);
+        if (a == b) return;
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        const int old = atomicMin(&M[hi], lo);
+        if (old == hi) return;
+        a = old; b = lo;
+    }
+}
+
 // merge request found by validation: particles pa, pb must be in one cluster (slot ids are filled in next round)
 AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
 {
