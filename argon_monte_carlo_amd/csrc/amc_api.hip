@@ -44,6 +44,11 @@ void amc_prof_end(amc_ctx *c)
     c->ev_used++;
     if (c->ev_used >= 4096) amc_prof_collect(c);
 }
+void amc_prof_cancel(amc_ctx *c)        // drop the open bracket (nothing was launched inside it)
+{
+    if (!c->profiling || c->ev_pending.empty()) return;
+    c->ev_pending.pop_back();
+}
 void amc_prof_collect(amc_ctx *c)
 {
     if (!c->profiling || c->ev_pending.empty()) return;

@@ -169,6 +169,7 @@ int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
 // profiling brackets
 void amc_prof_begin(amc_ctx *c, int kclass);
 void amc_prof_end(amc_ctx *c);
+void amc_prof_cancel(amc_ctx *c);
 void amc_prof_collect(amc_ctx *c);
 
 // stage bits of the streaming kernel

@@ -607,7 +607,7 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     }
     rs_args Aw = A;
     Aw.wide_plan = 1;
-    amc_prof_end(c);
+    amc_prof_cancel(c);                 // (the caller's bracket is re-opened below, around the kernel it is named after)
     amc_prof_begin(c, AMC_K_PAIRS_WIDE);
     hipLaunchKernelGGL((k_pairs_wide<GEOM>), dim3(64), dim3(256), 0, c->stream, Aw);
     amc_prof_end(c);
