@@ -776,3 +776,37 @@ def test_tolerated_fp_events_match_oracle(Engine, O):
         with pytest.raises(Exception):
             eng.timestep(c["dt"])
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- large-sweep launch plan
+@pytest.mark.parametrize("kind,n", [("cube", 400_000), ("pore", 1_000_000)])
+def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
+    """Sweeps with more than 640 candidates take the large plan: isolated pairs in k_pairs_wide, the entangled rest in
+    the ordered workgroup, wide validation, continuation, wide commit.  State and counters equal the oracle's bit for
+    bit at every step, and the profile shows that the wide pair kernel really ran."""
+    if kind == "cube":
+        p, c = PR.cube_params_for_n(n)
+        init = IC.cube_ic(p, c, seed=127)
+    else:
+        p, c = PR.pore_params(n=n)
+        init = IC.pore_ic(p, c, seed=17)
+    p.reserved1 = 1
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 20)
+    eng.upload(*init)
+    orc.upload(*init)
+    eng.profile(True)
+    ncand = 0
+    for s in range(6):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"):
+            assert st[k] == so[k], (kind, s, k, st, so)
+        ncand = max(ncand, st["n_candidates"])
+        assert_state_equal(eng.download(), orc.state(), ("large plan", kind, s))
+    kt = eng.kernel_times()
+    eng.profile(False)
+    assert ncand > 640
+    assert kt["pairs_wide"][1] >= 4 and kt["validate"][1] >= 4 and kt["commit"][1] >= 4, kt
+    eng.close()
