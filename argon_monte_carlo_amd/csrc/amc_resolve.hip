@@ -49,6 +49,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     __shared__ rs_shared sh;
     __shared__ int wide_ns;             // slots made by the wide pair kernel in this sweep, -1 if it did not run
+    __shared__ int wide_nh;             // history entries it made (already in the overlay lists)
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
     __shared__ double pool_d[10][RS_POOL];
     __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL], pool_slot[RS_POOL];
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     amc_dev_counters *cnt = A.O.cnt;
     rs_shared *ctl = (rs_shared *)W.ctl;
     int ncand;
-    if (threadIdx.x == 0) wide_ns = -1;
+    if (threadIdx.x == 0) { wide_ns = -1; wide_nh = 0; }
     if (MODE == 1) {
         if (tid == 0) sh = *ctl;
         __syncthreads();
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
                 sh.nhist = wc->nhist; sh.nev = wc->nev; sh.nfp = wc->nfp; sh.ovf = wc->ovf;
                 wide_ns = wc->active ? sh.nslots : -1;             // (>= 0: the wide kernel ran, W.cand_done is valid)
+                wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
                 wc->nslots = 0; wc->nhist = 0; wc->nev = 0; wc->nfp = 0; wc->ovf = 0; wc->active = 0; wc->cur_round = 1;
             }
             sh.nslots0 = 0;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
             if (V.label != W.sl_label)
                 for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
-            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            for (int h = (sh.hist_begin > wide_nh ? sh.hist_begin : wide_nh) + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
             if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.nslots0 = ns; *ctl = sh; }
             RS_STAMP(4);
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         // ---- validate: every new position against everything outside its cluster ------------------------------------------------
         if (!A.allpairs) {
-            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            for (int h = (sh.hist_begin > wide_nh ? sh.hist_begin : wide_nh) + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
             if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[14] += n__ - t_last; }
             for (int h = sh.hist_begin + tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);

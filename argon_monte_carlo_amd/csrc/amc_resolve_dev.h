@@ -129,6 +129,15 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     if (h + 1 < W.max_hist) {
         W.hist[h] = rs_hist_make(p1.x, p1.y, p1.z, sj, sh->cur_round);
         W.hist[h + 1] = rs_hist_make(p2.x, p2.y, p2.z, si, sh->cur_round);
+        if (!A.allpairs && !__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)sh)) {
+            // wide pair kernel (its counters live in global memory): the new positions go into the overlay lists right
+            // here, from thousands of waves, instead of one by one from the ordered workgroup's single CU later
+            int cx, cy, cz;
+            amc_grid_coords(A.G, p1.x, p1.y, p1.z, cx, cy, cz);
+            W.ov_next[h] = atomicExch(&W.ov_head[amc_grid_cell(A.G, cx, cy, cz, nullptr)], h);
+            amc_grid_coords(A.G, p2.x, p2.y, p2.z, cx, cy, cz);
+            W.ov_next[h + 1] = atomicExch(&W.ov_head[amc_grid_cell(A.G, cx, cy, cz, nullptr)], h + 1);
+        }
     } else {
         sh->ovf = 1;
     }
