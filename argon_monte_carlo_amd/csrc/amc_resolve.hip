@@ -50,6 +50,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     __shared__ rs_shared sh;
     __shared__ int wide_ns;             // slots made by the wide pair kernel in this sweep, -1 if it did not run
     __shared__ int wide_nh;             // history entries it made (already in the overlay lists)
+    __shared__ int s_heads[64], s_nheads;   // first member of every multi-particle cluster when all waves share them
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
     __shared__ double pool_d[10][RS_POOL];
     __shared__ int pool_tmp[RS_POOL], pool_pidx[RS_POOL], pool_slot[RS_POOL];
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         const int edges_new = edges_done;
         edges_done = nedges;
-        if (tid == 0) { sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
+        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
         __syncthreads();
         if (first) {
             // ---- connected components by label propagation (label = lowest slot id of the cluster); the pairs the wide
@@ -274,16 +275,16 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                     }
                     w0 = e;
                 }
-            } else if (is_head) {
-                const unsigned lab = (unsigned)(sorted[w] >> 32);
-                int e = w + 1;
-                while (e < nc && (unsigned)(sorted[e] >> 32) == lab) e++;
-                if (e - w >= 2) rs_emulate_generic(A, &sh, K, w, e);
+            } else {
+                // three or more clusters: every wave of the workgroup takes its share of them after the pair phase
+                // (below) — each cluster by a whole wave again; this wave only publishes where the clusters start
+                if (is_head) s_heads[__popcll(__ballot(is_head) & ((1ULL << w) - 1ULL))] = w;
+                if (w == 0) s_nheads = nheads;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[3] += n__ - t_last; t_last = n__; }
-            if (w < nc && K.moved[w]) rs_store_slot(W, K.slot[w], rs_load_work(K, w));
+            if (nheads <= 2 && w < nc && K.moved[w]) rs_store_slot(W, K.slot[w], rs_load_work(K, w));
         } else {
             // ---- two-particle clusters straight from the candidate list, both particles in registers ------------------------
             const int t0 = split ? tid - 64 : tid, tstride = split ? RS_T - 64 : RS_T;
@@ -297,6 +298,22 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         RS_STAMP(7);
         __syncthreads();
+        if (split && s_nheads > 2) {
+            const unsigned long long *sorted = lds_keys + RS_SORT_LDS / 2;
+            for (int hx = tid >> 6; hx < s_nheads; hx += RS_T / 64) {           // wave-uniform: one cluster per wave and turn
+                const int w0 = s_heads[hx];
+                const unsigned lab = (unsigned)(sorted[w0] >> 32);
+                int e = w0 + 1;
+                while (e < nc && (unsigned)(sorted[e] >> 32) == lab) e++;
+                if (e - w0 >= 2) {
+                    if (e - w0 <= RS_COOP_MAX) rs_emulate_coop(A, &sh, K, w0, e);
+                    else if ((tid & 63) == 0) rs_emulate_generic(A, &sh, K, w0, e);
+                }
+            }
+            __syncthreads();
+            if (tid < nc && K.moved[tid]) rs_store_slot(W, K.slot[tid], rs_load_work(K, tid));
+            __syncthreads();
+        }
         RS_STAMP(2);
         // ---- larger clusters: sort members by (label, index), working set in LDS when it fits ----------------------------
         if (nc > 0 && !split) {
