@@ -691,7 +691,12 @@ static void rs_launch_round(amc_ctx *c, rs_args A, int first)
     A.allow_mono = 0;           // the host drives the rounds (state exchange between them)
     if (first) {
         hipLaunchKernelGGL(k_gather_cst, dim3(64), dim3(256), 0, c->stream, A);
+        if (c->plan_split) {            // large sweep: the isolated pairs first, on the whole chip (same plan as single-GPU)
+            A.wide_plan = 1;
+            hipLaunchKernelGGL((k_pairs_wide<GEOM>), dim3(64), dim3(256), 0, c->stream, A);
+        }
         hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
+        A.wide_plan = 0;
     } else {
         A.single_round = 1;
         hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);

@@ -51,7 +51,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("kind,n,steps", [("cube", 30000, 8), ("pore", 60001, 6)])      # equal and unequal shards
+@pytest.mark.parametrize("kind,n,steps", [("cube", 30000, 8), ("pore", 60001, 6), ("cube", 400000, 5)])      # equal / unequal shards; large-sweep plan
 def test_two_ranks_one_gpu_equal_single_engine(kind, n, steps):
     from argon_monte_carlo_amd.engine import Engine
     p, c, init = _case(kind, n)
