@@ -9,7 +9,7 @@
 #include <algorithm>
 #include <new>
 
-#include "amc_internal.h"
+#include "amc_host.h"
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...)
 {
@@ -65,14 +65,6 @@ void amc_prof_collect(amc_ctx *c)
 }
 
 // ---- helpers ------------------------------------------------------------------------------------------------------------
-template <class T>
-static hipError_t dalloc(T **p, size_t count)
-{
-    *p = nullptr;
-    if (count == 0) count = 1;
-    return hipMalloc((void **)p, sizeof(T) * count);
-}
-
 static int next_pow2(int v)
 {
     int m = 1;
@@ -147,7 +139,6 @@ static int setup_grid(amc_ctx *c)
     return AMC_OK;
 }
 
-static int amc_flush(amc_ctx *c);
 
 extern "C" {
 
@@ -433,35 +424,6 @@ int amc_download_prior(amc_ctx *c, double *px, double *py, double *pz)
 }
 
 // ---- the step ----------------------------------------------------------------------------------------------------------
-// Small device -> host read-backs go through the pinned staging buffer: queue any number of pieces, synchronise once,
-// then copy out.  (Falls back to direct copies when a piece does not fit.)
-struct amc_stage {
-    amc_ctx *c;
-    size_t off = 0;
-    struct piece { void *dst; size_t off, bytes; };
-    std::vector<piece> pieces;
-    explicit amc_stage(amc_ctx *ctx) : c(ctx) {}
-    hipError_t get(void *dst, const void *src, size_t bytes)
-    {
-        if (!bytes) return hipSuccess;
-        c->mg_prefix = 0;                       // the staging area is being reused
-        const size_t at = (off + 63) & ~(size_t)63;
-        if (!c->h_pin || at + bytes > c->h_pin_bytes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
-        pieces.push_back({dst, at, bytes});
-        off = at + bytes;
-        return hipMemcpyAsync(c->h_pin + at, src, bytes, hipMemcpyDeviceToHost, c->stream);
-    }
-    hipError_t finish()
-    {
-        const hipError_t e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess)
-            for (auto &p : pieces) memcpy(p.dst, c->h_pin + p.off, p.bytes);
-        pieces.clear();
-        off = 0;
-        return e;
-    }
-};
-
 static void fold_banks(amc_dev_counters *h, const amc_counter_bank *b)
 {
     for (int k = 0; k < AMC_COUNTER_BANKS; k++) {
@@ -470,7 +432,7 @@ static void fold_banks(amc_dev_counters *h, const amc_counter_bank *b)
     }
 }
 
-static int read_counters(amc_ctx *c, amc_dev_counters *h)
+int amc_read_counters(amc_ctx *c, amc_dev_counters *h)
 {
     amc_counter_bank banks[AMC_COUNTER_BANKS];
     amc_stage st(c);
@@ -495,10 +457,10 @@ static void delta_stats(const amc_dev_counters &now, const amc_dev_counters &pre
     o->flags = (int64_t)now.flags;
 }
 
-static int finish_stats(amc_ctx *c, amc_step_stats *out)
+int amc_finish_stats(amc_ctx *c, amc_step_stats *out)
 {
     amc_dev_counters now;
-    int rc = read_counters(c, &now);
+    int rc = amc_read_counters(c, &now);
     if (rc) return rc;
     amc_step_stats st;
     delta_stats(now, c->h_prev, &st);
@@ -519,7 +481,7 @@ static int finish_stats(amc_ctx *c, amc_step_stats *out)
 }
 
 // sweep results deferred to the next streaming pass: write them now (before anything else reads the particle arrays)
-static int amc_flush(amc_ctx *c)
+int amc_flush(amc_ctx *c)
 {
     if (!c->lazy_pending) return AMC_OK;
     AMC_HIP(c, amc_launch_apply(c));
@@ -527,7 +489,7 @@ static int amc_flush(amc_ctx *c)
     return AMC_OK;
 }
 
-static int enqueue_sweep(amc_ctx *c, bool counted = false, bool defer_commit = false)
+int amc_enqueue_sweep(amc_ctx *c, bool counted, bool defer_commit)
 {
     if (!counted) AMC_HIP(c, amc_launch_bin(c));
     AMC_HIP(c, amc_launch_detect(c));
@@ -544,7 +506,7 @@ static int enqueue_step(amc_ctx *c, double dt, bool fold_prev_bounds = false, bo
     const int g = c->P.geometry;
     int rc;
     if (g == AMC_GEOM_CELL) {
-        if ((rc = enqueue_sweep(c))) return rc;
+        if ((rc = amc_enqueue_sweep(c))) return rc;
     } else if (g == AMC_GEOM_CUBE || g == AMC_GEOM_PORE) {
         // the streaming pass also counts the particles into the detection grid when it covers all of them
         const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
@@ -553,7 +515,7 @@ static int enqueue_step(amc_ctx *c, double dt, bool fold_prev_bounds = false, bo
         AMC_HIP(c, amc_launch_stream(c, dt, st, 0, fuse));
         // the scattered commit is deferred: the next streaming pass over all particles (the bounds check for the pore,
         // the next step's drift for the cube) picks the results up through slot_of[]
-        if ((rc = enqueue_sweep(c, fuse, c->lo == 0 && c->hi == c->n))) return rc;
+        if ((rc = amc_enqueue_sweep(c, fuse, c->lo == 0 && c->hi == c->n))) return rc;
         if (g == AMC_GEOM_PORE && !defer_bounds) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));
     } else {
         return amc_fail(c, AMC_ERR_INVALID, "energised walls need the host handshake: use the Python driver (amc_wall_hits/apply)");
@@ -569,7 +531,7 @@ int amc_timestep(amc_ctx *c, double dt, amc_step_stats *out)
     AMC_HIP(c, hipSetDevice(c->device));
     int rc = enqueue_step(c, dt);
     if (rc) return rc;
-    return finish_stats(c, out);
+    return amc_finish_stats(c, out);
 }
 
 int amc_run(amc_ctx *c, double dt, int64_t nsteps, amc_step_stats *sum)
@@ -583,7 +545,7 @@ int amc_run(amc_ctx *c, double dt, int64_t nsteps, amc_step_stats *sum)
         int rc = enqueue_step(c, dt, fold && s > 0, fold && s + 1 < nsteps);
         if (rc) return rc;
     }
-    return finish_stats(c, sum);
+    return amc_finish_stats(c, sum);
 }
 
 int amc_stage_drift(amc_ctx *c, double dt)
@@ -606,7 +568,7 @@ int amc_stage_walls(amc_ctx *c, amc_step_stats *out)
     AMC_HIP(c, hipSetDevice(c->device));
     { int rc_ = amc_flush(c); if (rc_) return rc_; }
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_WALLS, 0));
-    return finish_stats(c, out);
+    return amc_finish_stats(c, out);
 }
 
 int amc_stage_bounds(amc_ctx *c, int64_t *n_moved)
@@ -616,7 +578,7 @@ int amc_stage_bounds(amc_ctx *c, int64_t *n_moved)
     { int rc_ = amc_flush(c); if (rc_) return rc_; }
     AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));
     amc_step_stats st;
-    int rc = finish_stats(c, &st);
+    int rc = amc_finish_stats(c, &st);
     if (n_moved) *n_moved = st.n_oob_walls;
     return rc;
 }
@@ -626,9 +588,9 @@ int amc_stage_sweep(amc_ctx *c, amc_step_stats *out)
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
     { int rc_ = amc_flush(c); if (rc_) return rc_; }
-    int rc = enqueue_sweep(c);
+    int rc = amc_enqueue_sweep(c);
     if (rc) return rc;
-    return finish_stats(c, out);
+    return amc_finish_stats(c, out);
 }
 
 // ---- outputs ----------------------------------------------------------------------------------------------------------
@@ -637,7 +599,7 @@ int amc_paths_pending(amc_ctx *c, size_t *n)
     if (!c || !n) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
     amc_dev_counters now;
-    int rc = read_counters(c, &now);
+    int rc = amc_read_counters(c, &now);
     if (rc) return rc;
     *n = std::min<size_t>(now.path_count, c->out.cap);
     return AMC_OK;
@@ -671,7 +633,7 @@ int amc_histograms(amc_ctx *c, uint64_t *counts, uint64_t *n_paths_total)
         AMC_HIP(c, hipMemcpyAsync(banks.data(), c->d_hist, sizeof(uint64_t) * banks.size(), hipMemcpyDeviceToHost, c->stream));
     }
     amc_dev_counters now;
-    int rc = read_counters(c, &now);        // (synchronises the stream)
+    int rc = amc_read_counters(c, &now);        // (synchronises the stream)
     if (rc) return rc;
     if (counts) {
         const size_t m = (size_t)4 * c->out.nbins;
@@ -774,518 +736,6 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
         if (launches) launches[k] = c->k_launches[k];
     }
     return AMC_OK;
-}
-
-// ---- energised walls (Temp) ---------------------------------------------------------------------------------------------
-static int temp_ensure(amc_ctx *c)
-{
-    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "energised-wall calls need AMC_GEOM_PORE_ENERGISED");
-    if (c->T.idx) return AMC_OK;
-    amc_temp_ws &T = c->T;
-    T.cap = (int)std::min<int64_t>(std::max<int64_t>(4096, c->n / 8 + 1024), 0x3fffffff);
-    const size_t cap = (size_t)T.cap;
-    AMC_HIP(c, dalloc(&T.idx, cap)); AMC_HIP(c, dalloc(&T.count, 1)); AMC_HIP(c, dalloc(&T.t, cap));
-    AMC_HIP(c, dalloc(&T.contact, 3 * cap)); AMC_HIP(c, dalloc(&T.normal, 3 * cap)); AMC_HIP(c, dalloc(&T.dir, 3 * cap));
-    AMC_HIP(c, dalloc(&T.Es, cap)); AMC_HIP(c, dalloc(&T.dpz, cap)); AMC_HIP(c, dalloc(&T.dE, cap)); AMC_HIP(c, dalloc(&T.ok, cap));
-    T.last_case = -1; T.last_n = 0;
-    return AMC_OK;
-}
-
-int amc_temp_begin(amc_ctx *c, double dt)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_ensure(c);
-    if (rc) return rc;
-    if ((rc = amc_flush(c))) return rc;
-    c->keep_prior = true;       // the energised masks read prior_*_vals (Temp:708-750)
-    AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
-    return AMC_OK;
-}
-
-int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, size_t cap, size_t *n)
-{
-    if (!c || !n || case_id < 3 || case_id > 9) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_ensure(c);
-    if (rc) return rc;
-    amc_temp_ws &T = c->T;
-    AMC_HIP(c, amc_launch_temp_hits(c, case_id));
-    int cnt = 0;
-    amc_stage stg(c);
-    AMC_HIP(c, stg.get(&cnt, T.count, sizeof cnt));
-    AMC_HIP(c, stg.finish());
-    if (cnt > T.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits exceed the record capacity %d", cnt, T.cap);
-    if ((size_t)cnt > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits, caller buffer holds %zu", cnt, cap);
-    T.last_case = case_id; T.last_n = cnt;
-    T.perm.resize((size_t)cnt);
-    *n = (size_t)cnt;
-    if (cnt == 0) return AMC_OK;
-    std::vector<int> hidx((size_t)cnt);
-    std::vector<double> hnorm(3 * (size_t)cnt), hcontact(3 * (size_t)cnt);
-    AMC_HIP(c, stg.get(hidx.data(), T.idx, sizeof(int) * cnt));
-    AMC_HIP(c, stg.get(hnorm.data(), T.normal, sizeof(double) * 3 * cnt));
-    AMC_HIP(c, stg.get(hcontact.data(), T.contact, sizeof(double) * 3 * cnt));
-    AMC_HIP(c, stg.finish());
-    for (int k = 0; k < cnt; k++) T.perm[k] = k;
-    std::sort(T.perm.begin(), T.perm.end(), [&](int a, int b) { return hidx[a] < hidx[b]; });   // ascending particle index
-    for (int s = 0; s < cnt; s++) {
-        const int k = T.perm[s];
-        if (idx) idx[s] = hidx[k];
-        if (normal_xyz) { normal_xyz[3 * s] = hnorm[3 * k]; normal_xyz[3 * s + 1] = hnorm[3 * k + 1]; normal_xyz[3 * s + 2] = hnorm[3 * k + 2]; }
-        if (contact_z) contact_z[s] = hcontact[3 * k + 2];
-    }
-    return AMC_OK;
-}
-
-int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double *surface_energy, size_t n, double *dpz, double *dE)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    amc_temp_ws &T = c->T;
-    if (!T.idx || T.last_case != case_id || (size_t)T.last_n != n)
-        return amc_fail(c, AMC_ERR_STATE, "amc_wall_apply(case %d, n=%zu) does not match the pending amc_wall_hits(case %d, n=%d)", case_id, n, T.last_case, T.last_n);
-    T.last_case = -1;
-    if (n == 0) return AMC_OK;
-    if (!dir_xyz || !surface_energy) return AMC_ERR_INVALID;
-    // caller order (ascending particle index) -> record order
-    std::vector<double> hdir(3 * n), hEs(n);
-    for (size_t s = 0; s < n; s++) {
-        const int k = T.perm[s];
-        hdir[3 * k] = dir_xyz[3 * s]; hdir[3 * k + 1] = dir_xyz[3 * s + 1]; hdir[3 * k + 2] = dir_xyz[3 * s + 2];
-        hEs[k] = surface_energy[s];
-    }
-    AMC_HIP(c, hipMemcpyAsync(T.dir, hdir.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    AMC_HIP(c, hipMemcpyAsync(T.Es, hEs.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n));
-    std::vector<double> hp(n), he(n);
-    amc_stage stg(c);
-    AMC_HIP(c, stg.get(hp.data(), T.dpz, sizeof(double) * n));
-    AMC_HIP(c, stg.get(he.data(), T.dE, sizeof(double) * n));
-    AMC_HIP(c, stg.finish());
-    for (size_t s = 0; s < n; s++) {
-        if (dpz) dpz[s] = hp[T.perm[s]];
-        if (dE) dE[s] = he[T.perm[s]];
-    }
-    return AMC_OK;
-}
-
-// ---- device-RNG mode ---------------------------------------------------------------------------------------------------------
-static int temp_dev_ensure(amc_ctx *c)
-{
-    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "energised-wall calls need AMC_GEOM_PORE_ENERGISED");
-    amc_temp_dev_ws &D = c->TD;
-    if (D.idx) return AMC_OK;
-    D.cap = (int)std::min<int64_t>(std::max<int64_t>(4096, c->n / 64 + 1024), 0x0fffffff);
-    const size_t cap = (size_t)D.cap * 7;
-    AMC_HIP(c, dalloc(&D.idx, cap)); AMC_HIP(c, dalloc(&D.count, 8)); AMC_HIP(c, dalloc(&D.t, cap));
-    AMC_HIP(c, dalloc(&D.contact, 3 * cap)); AMC_HIP(c, dalloc(&D.normal, 3 * cap)); AMC_HIP(c, dalloc(&D.dir, 3 * cap));
-    AMC_HIP(c, dalloc(&D.Es, cap)); AMC_HIP(c, dalloc(&D.dpz, cap)); AMC_HIP(c, dalloc(&D.dE, cap)); AMC_HIP(c, dalloc(&D.ok, cap));
-    return AMC_OK;
-}
-
-int amc_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    if (!cfg || cfg->struct_size != (int32_t)sizeof(amc_temp_rng) || cfg->n_gl < 2 || cfg->n_gl > 32)
-        return amc_fail(c, AMC_ERR_INVALID, "amc_temp_rng: bad struct_size / n_gl");
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_dev_ensure(c);
-    if (rc) return rc;
-    if (!c->keep_prior) return amc_fail(c, AMC_ERR_STATE, "amc_temp_cases_device follows amc_temp_begin");
-    c->TD.fetched = false;
-    AMC_HIP(c, amc_launch_temp_cases_device(c, cfg));
-    return AMC_OK;
-}
-
-// counts of all seven cases and the head of every segment in one synchronisation; longer segments are completed here
-static int temp_dev_fetch(amc_ctx *c)
-{
-    amc_temp_dev_ws &D = c->TD;
-    if (D.fetched) return AMC_OK;
-    const int pre = std::min(D.cap, 2048);
-    {
-        amc_stage st(c);
-        AMC_HIP(c, st.get(D.h_count, D.count, sizeof(int) * 7));
-        for (int s = 0; s < 7; s++) {
-            const size_t o = (size_t)s * (size_t)D.cap;
-            D.h_idx[s].resize((size_t)pre); D.h_dpz[s].resize((size_t)pre); D.h_dE[s].resize((size_t)pre); D.h_ok[s].resize((size_t)pre);
-            AMC_HIP(c, st.get(D.h_idx[s].data(), D.idx + o, sizeof(int) * (size_t)pre));
-            AMC_HIP(c, st.get(D.h_dpz[s].data(), D.dpz + o, sizeof(double) * (size_t)pre));
-            AMC_HIP(c, st.get(D.h_dE[s].data(), D.dE + o, sizeof(double) * (size_t)pre));
-            AMC_HIP(c, st.get(D.h_ok[s].data(), D.ok + o, (size_t)pre));
-        }
-        AMC_HIP(c, st.finish());
-    }
-    for (int s = 0; s < 7; s++) {
-        if (D.h_count[s] > D.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits in case %d exceed the record capacity %d", D.h_count[s], 3 + s, D.cap);
-        const size_t k = (size_t)std::max(D.h_count[s], 0);
-        if ((int)k > pre) {
-            const size_t o = (size_t)s * (size_t)D.cap;
-            D.h_idx[s].resize(k); D.h_dpz[s].resize(k); D.h_dE[s].resize(k); D.h_ok[s].resize(k);
-            amc_stage st(c);
-            AMC_HIP(c, st.get(D.h_idx[s].data(), D.idx + o, sizeof(int) * k));
-            AMC_HIP(c, st.get(D.h_dpz[s].data(), D.dpz + o, sizeof(double) * k));
-            AMC_HIP(c, st.get(D.h_dE[s].data(), D.dE + o, sizeof(double) * k));
-            AMC_HIP(c, st.get(D.h_ok[s].data(), D.ok + o, k));
-            AMC_HIP(c, st.finish());
-        }
-    }
-    D.fetched = true;
-    return AMC_OK;
-}
-
-int amc_temp_device_results(amc_ctx *c, int case_id, int32_t *idx, double *dpz, double *dE, uint8_t *ok, size_t cap, size_t *n)
-{
-    if (!c || !n || case_id < 3 || case_id > 9 || !c->TD.idx) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_dev_fetch(c);
-    if (rc) return rc;
-    amc_temp_dev_ws &D = c->TD;
-    const int s = case_id - 3;
-    const size_t k = (size_t)std::max(D.h_count[s], 0);
-    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%zu wall hits, caller buffer holds %zu", k, cap);
-    std::vector<int> perm(k);
-    for (size_t u = 0; u < k; u++) perm[u] = (int)u;
-    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });   // ascending particle index
-    for (size_t u = 0; u < k; u++) {
-        const int r = perm[u];
-        if (idx) idx[u] = D.h_idx[s][r];
-        if (dpz) dpz[u] = D.h_dpz[s][r];
-        if (dE) dE[u] = D.h_dE[s][r];
-        if (ok) ok[u] = D.h_ok[s][r];
-    }
-    *n = k;
-    return AMC_OK;
-}
-
-int amc_temp_device_sums(amc_ctx *c, double *sums, int32_t *had)
-{
-    if (!c || !sums || !had || !c->TD.idx) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_dev_fetch(c);
-    if (rc) return rc;
-    amc_temp_dev_ws &D = c->TD;
-    sums[0] = sums[1] = sums[2] = 0.0;
-    had[0] = had[1] = had[2] = 0;
-    std::vector<int> perm;
-    for (int s = 0; s < 7; s++) {
-        const int case_id = 3 + s;
-        const size_t k = (size_t)std::max(D.h_count[s], 0);
-        if (!k) continue;
-        perm.resize(k);
-        for (size_t u = 0; u < k; u++) perm[u] = (int)u;
-        std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });
-        double m_case = 0.0, e_case = 0.0;
-        bool any = false;
-        for (size_t u = 0; u < k; u++) {
-            const int r = perm[u];
-            if (!D.h_ok[s][r]) continue;
-            m_case = m_case + D.h_dpz[s][r];
-            e_case = e_case + D.h_dE[s][r];
-            any = true;
-        }
-        sums[0] = sums[0] + m_case;
-        had[0] |= any ? 1 : 0;
-        const bool cold = (case_id == 3 || case_id == 7 || case_id == 9), hot = (case_id == 4 || case_id == 6 || case_id == 8);
-        if (cold) { sums[1] = sums[1] + e_case; had[1] |= any ? 1 : 0; }
-        if (hot) { sums[2] = sums[2] + e_case; had[2] |= any ? 1 : 0; }
-    }
-    return AMC_OK;
-}
-
-int amc_temp_device_draws(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
-                          double *surface_energy, size_t cap, size_t *n)
-{
-    if (!c || !n || case_id < 3 || case_id > 9 || !c->TD.idx) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = temp_dev_fetch(c);
-    if (rc) return rc;
-    amc_temp_dev_ws &D = c->TD;
-    const int s = case_id - 3;
-    const size_t k = (size_t)std::max(D.h_count[s], 0), o = (size_t)s * (size_t)D.cap;
-    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%zu wall hits, caller buffer holds %zu", k, cap);
-    *n = k;
-    if (!k) return AMC_OK;
-    std::vector<double> hn(3 * k), hc(3 * k), hd(3 * k), he(k);
-    AMC_HIP(c, hipMemcpy(hn.data(), D.normal + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
-    AMC_HIP(c, hipMemcpy(hc.data(), D.contact + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
-    AMC_HIP(c, hipMemcpy(hd.data(), D.dir + 3 * o, sizeof(double) * 3 * k, hipMemcpyDeviceToHost));
-    AMC_HIP(c, hipMemcpy(he.data(), D.Es + o, sizeof(double) * k, hipMemcpyDeviceToHost));
-    std::vector<int> perm(k);
-    for (size_t u = 0; u < k; u++) perm[u] = (int)u;
-    std::sort(perm.begin(), perm.end(), [&](int a, int b) { return D.h_idx[s][a] < D.h_idx[s][b]; });
-    for (size_t u = 0; u < k; u++) {
-        const int r = perm[u];
-        if (idx) idx[u] = D.h_idx[s][r];
-        for (int e = 0; e < 3; e++) {
-            if (normal_xyz) normal_xyz[3 * u + e] = hn[3 * r + e];
-            if (dir_xyz) dir_xyz[3 * u + e] = hd[3 * r + e];
-        }
-        if (contact_z) contact_z[u] = hc[3 * r + 2];
-        if (surface_energy) surface_energy[u] = he[r];
-    }
-    return AMC_OK;
-}
-
-int amc_temp_end(amc_ctx *c, amc_step_stats *out)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    AMC_HIP(c, hipSetDevice(c->device));
-    if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "amc_temp_end needs AMC_GEOM_PORE_ENERGISED");
-    // the bounds pass before the sweep sees every particle at its final pre-sweep position: it builds the detection
-    // grid's lists as well (like the fused streaming pass of the specular geometries)
-    const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;
-    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0, fuse));  // Temp:804
-    int rc = enqueue_sweep(c, fuse);                                // Temp:813-842
-    if (rc) return rc;
-    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));        // Temp:844
-    c->out.step++;
-    return finish_stats(c, out);
-}
-
-int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
-{
-    if (!c || lo < 0 || hi < lo || hi > c->n) return AMC_ERR_INVALID;
-    c->lo = lo; c->hi = hi;
-    c->mg_count_pp = (lo == 0);     // the rank that owns particle 0 reports the sweep's collision count
-    return AMC_OK;
-}
-
-static int mg_ensure_xchg(amc_ctx *c)
-{
-    if (c->xchg_send) return AMC_OK;
-    c->xchg_stride = std::max<int64_t>(c->W.max_slots, 1024);
-    AMC_HIP(c, hipMalloc(&c->xchg_send, sizeof(double) * 11 * (size_t)c->xchg_stride));
-    AMC_HIP(c, hipMalloc(&c->xchg_recv, sizeof(int) * (size_t)c->xchg_stride));
-    return AMC_OK;
-}
-
-int amc_device_view_get(amc_ctx *c, amc_device_view *out)
-{
-    if (!c || !out) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = mg_ensure_xchg(c);
-    if (rc) return rc;
-    out->x = c->S.x; out->y = c->S.y; out->z = c->S.z;
-    out->xchg = c->xchg_send; out->xchg_capacity = c->xchg_stride;
-    out->n = c->n; out->lo = c->lo; out->hi = c->hi;
-    return AMC_OK;
-}
-
-int amc_mg_local(amc_ctx *c, double dt)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    { int rc_ = amc_flush(c); if (rc_) return rc_; }
-    if (c->allpairs || c->P.geometry == AMC_GEOM_CELL || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
-        return amc_fail(c, AMC_ERR_INVALID, "multi-GPU needs the binned detector and the cube / specular pore geometry");
-    AMC_HIP(c, hipSetDevice(c->device));
-    const int st = (c->P.geometry == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
-    AMC_HIP(c, amc_launch_stream(c, dt, st, 0));
-    return AMC_OK;
-}
-
-int amc_mg_positions_view(amc_ctx *c, int world, void **send, void **recv, int64_t *m)
-{
-    if (!c || world < 1 || !send || !recv || !m) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    if (c->pos_world != world) {
-        { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
-      for (void *q : td) if (q) hipFree(q); }
-    if (c->pos_send) hipFree(c->pos_send);
-        if (c->pos_recv) hipFree(c->pos_recv);
-        c->pos_send = c->pos_recv = nullptr;
-        c->pos_m = (c->n + world - 1) / world;
-        const size_t mm = (size_t)std::max<int64_t>(c->pos_m, 1);
-        AMC_HIP(c, hipMalloc((void **)&c->pos_send, sizeof(double) * 3 * mm));
-        AMC_HIP(c, hipMalloc((void **)&c->pos_recv, sizeof(double) * 3 * mm * (size_t)world));
-        c->pos_world = world;
-    }
-    *send = c->pos_send; *recv = c->pos_recv; *m = c->pos_m;
-    return AMC_OK;
-}
-
-int amc_mg_pack_positions(amc_ctx *c, int world)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    if (world != c->pos_world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_positions_view(world=%d) has not been called", world);
-    AMC_HIP(c, hipSetDevice(c->device));
-    // this rank's range must be the driver's shard of that world size (the unpack side recomputes the ranges)
-    AMC_HIP(c, amc_launch_pos_pack(c, world, 0, 0));
-    return AMC_OK;
-}
-
-int amc_mg_unpack_positions(amc_ctx *c, int world, int rank)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    if (world != c->pos_world || rank < 0 || rank >= world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_unpack_positions: world/rank do not match amc_mg_positions_view");
-    const int64_t base = c->n / world, rem = c->n % world;
-    const int64_t lo = rank * base + std::min<int64_t>(rank, rem), hi = lo + base + (rank < rem ? 1 : 0);
-    if (lo != c->lo || hi != c->hi) return amc_fail(c, AMC_ERR_STATE, "rank %d of %d owns [%lld,%lld), amc_set_shard says [%lld,%lld)", rank, world, (long long)lo, (long long)hi, (long long)c->lo, (long long)c->hi);
-    AMC_HIP(c, hipSetDevice(c->device));
-    AMC_HIP(c, amc_launch_pos_pack(c, world, rank, 1));
-    return AMC_OK;
-}
-
-int amc_mg_detect(amc_ctx *c, int64_t *n_candidates)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    AMC_HIP(c, hipSetDevice(c->device));
-    AMC_HIP(c, amc_launch_bin(c));
-    AMC_HIP(c, amc_launch_detect(c));
-    // the counters and the head of the candidate list in one synchronisation (amc_mg_candidates then needs none)
-    amc_dev_counters now;
-    c->mg_prefix = 0;
-    const int pre = std::min(c->W.max_cand, 8192);
-    if (c->h_pin && c->h_pin_bytes >= 4096 + 2 * sizeof(int) * (size_t)pre) {
-        AMC_HIP(c, hipMemcpyAsync(c->h_pin, c->d_cnt, sizeof now, hipMemcpyDeviceToHost, c->stream));
-        AMC_HIP(c, hipMemcpyAsync(c->h_pin + 4096, c->W.cand_i, sizeof(int) * (size_t)pre, hipMemcpyDeviceToHost, c->stream));
-        AMC_HIP(c, hipMemcpyAsync(c->h_pin + 4096 + sizeof(int) * (size_t)pre, c->W.cand_j, sizeof(int) * (size_t)pre, hipMemcpyDeviceToHost, c->stream));
-        AMC_HIP(c, hipStreamSynchronize(c->stream));
-        memcpy(&now, c->h_pin, sizeof now);
-        c->mg_prefix = pre;
-    } else {
-        int rc = read_counters(c, &now);
-        if (rc) return rc;
-    }
-    if (now.cand_count > (unsigned)c->W.max_cand) return amc_fail(c, AMC_ERR_CAPACITY, "candidate list overflow (%u)", now.cand_count);
-    if (n_candidates) *n_candidates = now.cand_count;
-    c->mg_ncand = (int)now.cand_count;
-    return AMC_OK;
-}
-
-int amc_mg_candidates(amc_ctx *c, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n)
-{
-    if (!c || !n) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    const size_t k = std::min<size_t>((size_t)std::max(c->mg_ncand, 0), (size_t)c->W.max_cand);   // from amc_mg_detect
-    if (k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "amc_mg_candidates: %zu pairs, buffer holds %zu", k, cap);
-    if (k && (int)k <= c->mg_prefix) {          // staged by amc_mg_detect
-        memcpy(cand_i, c->h_pin + 4096, sizeof(int) * k);
-        memcpy(cand_j, c->h_pin + 4096 + sizeof(int) * (size_t)c->mg_prefix, sizeof(int) * k);
-    } else if (k) {
-        amc_stage stg(c);
-        AMC_HIP(c, stg.get(cand_i, c->W.cand_i, sizeof(int) * k));
-        AMC_HIP(c, stg.get(cand_j, c->W.cand_j, sizeof(int) * k));
-        AMC_HIP(c, stg.finish());
-    }
-    c->mg_prefix = 0;
-    *n = k;
-    return AMC_OK;
-}
-
-static int mg_upload_list(amc_ctx *c, const int32_t *particles, size_t n)
-{
-    int rc = mg_ensure_xchg(c);
-    if (rc) return rc;
-    if ((int64_t)n > c->xchg_stride) return amc_fail(c, AMC_ERR_CAPACITY, "exchange list of %zu particles exceeds capacity %lld", n, (long long)c->xchg_stride);
-    if (n) AMC_HIP(c, hipMemcpyAsync(c->xchg_recv, particles, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-    return AMC_OK;
-}
-
-int amc_mg_pack_state(amc_ctx *c, const int32_t *particles, size_t n)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = mg_upload_list(c, particles, n);
-    if (rc) return rc;
-    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 0));
-    return AMC_OK;
-}
-
-int amc_mg_unpack_state(amc_ctx *c, const int32_t *particles, size_t n)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    int rc = mg_upload_list(c, particles, n);
-    if (rc) return rc;
-    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 1));
-    return AMC_OK;
-}
-
-int amc_mg_exchange_begin(amc_ctx *c, const int32_t *particles, size_t n, size_t *n_rows)
-{
-    if (!c || !n_rows) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    std::vector<int32_t> list;
-    if (!particles) {
-        const size_t k = std::min<size_t>((size_t)std::max(c->mg_ncand, 0), (size_t)c->W.max_cand);
-        list.resize(2 * k);
-        if (k) {
-            int rc = amc_mg_candidates(c, list.data(), list.data() + k, k, &n);       // staged by amc_mg_detect: no device access
-            if (rc) return rc;
-        }
-        std::sort(list.begin(), list.end());
-        list.erase(std::unique(list.begin(), list.end()), list.end());                // canonical order: ascending particle index
-        particles = list.data();
-        n = list.size();
-    }
-    int rc = mg_upload_list(c, particles, n);
-    if (rc) return rc;
-    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)n, (double *)c->xchg_send, 0));
-    c->mg_list_n = n;
-    *n_rows = n;
-    return AMC_OK;
-}
-
-int amc_mg_exchange_end(amc_ctx *c)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    AMC_HIP(c, amc_launch_pack(c, (const int *)c->xchg_recv, (int)c->mg_list_n, (double *)c->xchg_send, 1));
-    return AMC_OK;
-}
-
-int amc_mg_resolve_round(amc_ctx *c, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new)
-{
-    if (!c || !dirty || !n_new) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    AMC_HIP(c, amc_launch_resolve_round(c, first));
-    amc_resolve_ctl ctl;
-    amc_stage stg(c);
-    AMC_HIP(c, stg.get(&ctl, c->W.ctl, sizeof ctl));
-    AMC_HIP(c, stg.finish());
-    *dirty = 0; *n_new = 0;
-    if (!ctl.active) return AMC_OK;
-    if (ctl.ovf) return amc_fail(c, AMC_ERR_CAPACITY, "resolve work space overflow");
-    *dirty = ctl.dirty != 0;
-    const int k = ctl.nslots - ctl.nslots0;
-    if (k > 0) {
-        if ((size_t)k > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d new cluster members, buffer holds %zu", k, cap);
-        AMC_HIP(c, stg.get(new_members, c->W.sl_p + ctl.nslots0, sizeof(int) * (size_t)k));
-        AMC_HIP(c, stg.finish());
-        std::sort(new_members, new_members + k);
-        *n_new = (size_t)k;
-    }
-    return AMC_OK;
-}
-
-int amc_mg_commit(amc_ctx *c)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    AMC_HIP(c, amc_launch_commit(c));
-    return AMC_OK;
-}
-
-int amc_mg_bounds(amc_ctx *c)
-{
-    if (!c || !c->uploaded) return AMC_ERR_STATE;
-    AMC_HIP(c, hipSetDevice(c->device));
-    { int rc_ = amc_flush(c); if (rc_) return rc_; }
-    AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 0));        // Temp:804 on the owned range, counters read later
-    return AMC_OK;
-}
-
-int amc_mg_finish(amc_ctx *c, amc_step_stats *out)
-{
-    if (!c) return AMC_ERR_INVALID;
-    AMC_HIP(c, hipSetDevice(c->device));
-    if (c->P.geometry == AMC_GEOM_PORE || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
-        AMC_HIP(c, amc_launch_stream(c, 0.0, AMC_ST_BOUNDS, 1));                     // Pore:550 / Temp:844
-    c->out.step++;
-    if (!out) return AMC_OK;        // asynchronous: the caller reads the counters later
-    return finish_stats(c, out);
 }
 
 }  // extern "C"
