@@ -810,3 +810,22 @@ def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
     assert ncand > 640
     assert kt["pairs_wide"][1] >= 4 and kt["validate"][1] >= 4 and kt["commit"][1] >= 4, kt
     eng.close()
+
+
+def test_candidate_overflow_in_the_large_sweep_plan_is_reported(Engine):
+    """Too small a candidate buffer with the detection grid and the large-sweep plan (wide pair kernel): every step
+    reports AMC_ERR_CAPACITY, nothing crashes, and the context stays usable for a following call."""
+    from argon_monte_carlo_amd._lib import ArgonMCError
+    p, c = PR.cube_params_for_n(400_000)
+    p.detect_mode = 1
+    p.max_candidates = 700                      # ~800 candidates per step at this size
+    init = IC.cube_ic(p, c, seed=127)
+    eng = Engine(p)
+    eng.upload(*init)
+    for s in range(3):                          # the first call runs the small plan (no history yet), the next ones the large one
+        with pytest.raises(ArgonMCError) as ei:
+            eng.timestep(c["dt"])
+        assert ei.value.code == -4, (s, ei.value)
+    st = eng.download()
+    assert np.all(np.isfinite(st["x"]))
+    eng.close()
