@@ -23,8 +23,10 @@
 //
 // The ordered logic runs in ONE 512-thread workgroup (phases separated by __syncthreads, counters in LDS): the data
 // set is a few hundred pairs, so the cost is latency, not throughput.  Everything that is scattered memory traffic
-// is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and the
-// first round's validation probes and the commit scatter are separate wide kernels.
+// is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and for
+// large sweeps (> 640 candidates) the isolated pairs are emulated by a wide kernel first (k_pairs_wide), the first
+// round's validation probes and the commit scatter are separate wide kernels, and only the entangled remainder and
+// the later rounds stay in the workgroup.  A multi-particle cluster is emulated by a whole wave (rs_emulate_coop).
 #include "amc_resolve_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
