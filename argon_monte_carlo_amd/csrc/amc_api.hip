@@ -428,7 +428,7 @@ static void fold_banks(amc_dev_counters *h, const amc_counter_bank *b)
 {
     for (int k = 0; k < AMC_COUNTER_BANKS; k++) {
         h->n_wall += b[k].n_wall; h->n_paths += b[k].n_paths; h->n_paths_total += b[k].n_paths_total;
-        h->n_fp_errors += b[k].n_fp_errors;
+        h->n_fp_errors += b[k].n_fp_errors; h->n_pp += b[k].n_pp;
     }
 }
 

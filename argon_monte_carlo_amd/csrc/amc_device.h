@@ -31,7 +31,7 @@ struct amc_dev_counters {
 // folds the banks into amc_dev_counters on the host.
 #define AMC_COUNTER_BANKS 64
 struct amc_counter_bank {
-    unsigned long long n_wall, n_paths, n_paths_total, n_fp_errors, pad[4];
+    unsigned long long n_wall, n_paths, n_paths_total, n_fp_errors, n_pp, pad[3];
 };
 // (readfirstlane: the id is the same for all lanes of a wave; telling the compiler so keeps its wave-level combining of
 // atomics on a uniform address, which otherwise turns one atomic per wave into one per lane)

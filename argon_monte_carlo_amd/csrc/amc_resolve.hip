@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     }
     // one atomic per wave instead of one per slot on a single counter word
     for (int o = 32; o > 0; o >>= 1) my_hits += __shfl_down(my_hits, o, 64);
-    if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(&A.O.cnt->n_pp, (unsigned long long)my_hits);
+    if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(&A.O.banks[amc_bank_id()].n_pp, (unsigned long long)my_hits);
     if (ok)
         for (int e = gtid; e < nev; e += gstride) {
             if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;          // event of an emulation that was redone since
