@@ -12,9 +12,10 @@ for w in cube_1e5 cube_1e6 pore_5e5 pore_1e6; do
 done
 timeout -k 10 300 python bench.py --workload temp_1e6 --steps 20 --warmup 2 > "$OUT/bench_temp_1e6.json" 2> "$OUT/bench_temp_1e6.err" || echo "bench temp failed"
 cd /tmp && export TMPDIR=/tmp
-for w in cube_1e5 pore_1e6; do
+for w in cube_1e5 pore_5e5 pore_1e6 cube_1e6 temp_1e6; do
+    steps=1000; [ $w = temp_1e6 ] && steps=20
     timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$w" -o out --output-format csv -- \
-        python "$R/bench.py" --workload $w --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/kt_$w.log" 2>&1 || echo "kernel trace $w failed"
+        python "$R/bench.py" --workload $w --steps $steps --warmup 5 --no-cpu-baseline > "$OUT/kt_$w.log" 2>&1 || echo "kernel trace $w failed"
     for c in FETCH_SIZE WRITE_SIZE; do
         timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace -d "$OUT/pmc_${c}_$w" -o out --output-format csv -- \
             python "$R/bench.py" --workload $w --steps 20 --warmup 2 --no-cpu-baseline > "$OUT/pmc_${c}_$w.log" 2>&1 || echo "pmc $c $w failed"
