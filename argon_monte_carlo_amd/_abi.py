@@ -1,7 +1,7 @@
 """ctypes mirror of include/argonmc.h (structs only; no library is loaded here)."""
 import ctypes as C
 
-AMC_ABI_VERSION = 1
+AMC_ABI_VERSION = 2
 
 AMC_OK = 0
 AMC_ERR_INVALID = -1
@@ -66,11 +66,6 @@ class AmcStepStats(C.Structure):
 class AmcPathRecord(C.Structure):
     _fields_ = [("step", C.c_int32), ("phase", C.c_int32), ("cell", C.c_int64), ("i", C.c_int32), ("j", C.c_int32),
                 ("which", C.c_int32), ("reserved", C.c_int32), ("total", _D), ("px", _D), ("py", _D), ("pz", _D)]
-
-
-class AmcDeviceView(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("xchg", C.c_void_p),
-                ("xchg_capacity", C.c_int64), ("n", C.c_int64), ("lo", C.c_int64), ("hi", C.c_int64)]
 
 
 class AmcTempRng(C.Structure):

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import (AMC_ABI_VERSION, AmcDeviceView, AmcParams, AmcPathRecord, AmcStepStats, AmcTempRng)
+from ._abi import (AMC_ABI_VERSION, AmcParams, AmcPathRecord, AmcStepStats, AmcTempRng)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libargonmc.so")
@@ -53,19 +53,10 @@ SIGNATURES = {
     "amc_histograms": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "amc_reset_outputs": (C.c_int, [_ctx]),
     "amc_set_shard": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
-    "amc_device_view_get": (C.c_int, [_ctx, C.POINTER(AmcDeviceView)]),
     "amc_mg_local": (C.c_int, [_ctx, C.c_double]),
-    "amc_mg_detect": (C.c_int, [_ctx, _i64p]),
-    "amc_mg_candidates": (C.c_int, [_ctx, _i32p, _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
-    "amc_mg_pack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
-    "amc_mg_unpack_state": (C.c_int, [_ctx, _i32p, C.c_size_t]),
-    "amc_mg_exchange_begin": (C.c_int, [_ctx, _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
-    "amc_mg_exchange_end": (C.c_int, [_ctx]),
-    "amc_mg_resolve_round": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_int), _i32p, C.c_size_t, C.POINTER(C.c_size_t)]),
-    "amc_mg_positions_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
-    "amc_mg_pack_positions": (C.c_int, [_ctx, C.c_int]),
-    "amc_mg_unpack_positions": (C.c_int, [_ctx, C.c_int, C.c_int]),
-    "amc_mg_commit": (C.c_int, [_ctx]),
+    "amc_mg_exchange_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "amc_mg_pack": (C.c_int, [_ctx, C.c_int]),
+    "amc_mg_sweep": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "amc_mg_bounds": (C.c_int, [_ctx]),
     "amc_mg_finish": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_profile": (C.c_int, [_ctx, C.c_int]),

@@ -164,7 +164,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
                     c->W.edge_b, c->W.hist, c->W.ov_head, c->W.ov_next,
                     c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->d_banks, c->xchg_send, c->xchg_recv, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
+                    c->d_edges, c->d_cnt, c->d_banks, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
@@ -175,8 +175,8 @@ void amc_destroy(amc_ctx *c)
     if (c->h_pin) hipHostFree(c->h_pin);
     { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
       for (void *q : td) if (q) hipFree(q); }
-    if (c->pos_send) hipFree(c->pos_send);
-    if (c->pos_recv) hipFree(c->pos_recv);
+    if (c->kin_send) hipFree(c->kin_send);
+    if (c->kin_recv) hipFree(c->kin_recv);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -220,9 +220,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->mg_count_pp = true;
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
-    c->mg_ncand = 0;
-    c->d_cnt = nullptr; c->xchg_send = c->xchg_recv = nullptr; c->xchg_stride = 0; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->mg_prefix = 0; c->mg_list_n = 0; c->plan_split = false;
-    c->pos_send = c->pos_recv = nullptr; c->pos_world = 0; c->pos_m = 0;
+    c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
+    c->kin_send = c->kin_recv = nullptr; c->kin_world = 0; c->kin_m = 0;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
     c->stream = nullptr;

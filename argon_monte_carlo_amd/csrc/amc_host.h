@@ -31,7 +31,6 @@ struct amc_stage {
     hipError_t get(void *dst, const void *src, size_t bytes)
     {
         if (!bytes) return hipSuccess;
-        c->mg_prefix = 0;                       // the staging area is being reused
         const size_t at = (off + 63) & ~(size_t)63;
         if (!c->h_pin || at + bytes > c->h_pin_bytes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
         pieces.push_back({dst, at, bytes});

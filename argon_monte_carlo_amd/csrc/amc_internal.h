@@ -138,24 +138,19 @@ struct amc_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<std::pair<int, int>> ev_pending;   // (kernel class, pool index)
     size_t ev_used;
-    // multi-GPU exchange
-    void *xchg_send, *xchg_recv;   // xchg_send = state table float64[11][n_list]; xchg_recv = int32 particle list
-    int64_t xchg_stride;           // capacity of both, in particles
+    // multi-GPU
     bool mg_count_pp;              // this rank adds the p-p collision count to its counters
     volatile int *h_host_ncand;    // host-mapped word written by k_resolve (candidate count of the last sweep)
     int *d_host_ncand;             // its device address
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
-    int mg_ncand;                  // candidate count read back by the last amc_mg_detect
-    size_t mg_list_n;              // rows of the exchange begun by amc_mg_exchange_begin
     unsigned int sweep_epoch;      // tag of the degree counts of the current sweep (advanced by every detect launch)
     bool plan_split;               // launch plan of the current sweep, fixed when its detect kernel is launched
     // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
     char *h_pin;
     size_t h_pin_bytes;
-    int mg_prefix;                 // candidates already staged in h_pin by amc_mg_detect
-    double *pos_send, *pos_recv;   // packed position exchange: [3][m] and [world][3][m]
-    int pos_world;
-    int64_t pos_m;
+    double *kin_send, *kin_recv;   // packed exchange of positions and velocities: [6][m] and [world][6][m]
+    int kin_world;
+    int64_t kin_m;
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
@@ -185,13 +180,10 @@ hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_apply(amc_ctx *c);                // write deferred sweep results to the particle arrays now
-hipError_t amc_launch_resolve_round(amc_ctx *c, int first);
-hipError_t amc_launch_commit(amc_ctx *c);
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
 hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg);
-hipError_t amc_launch_pos_pack(amc_ctx *c, int world, int rank, int unpack);
-hipError_t amc_launch_pack(amc_ctx *c, const int *d_list, int n, double *table, int unpack);
+hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack);
 // the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
 struct amc_resolve_ctl {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     // MODE 2 always, MODE 0 for small sweeps: validation and commit in this kernel (the wide kernels then find
     // ctl.active == 0 and exit); large sweeps hand over after the first round
-    const bool mono = (MODE == 2) || (MODE == 0 && A.allow_mono && (A.force_mono || ncand <= RS_SMALL));
+    const bool mono = (MODE == 2) || (MODE == 0 && (A.force_mono || ncand <= RS_SMALL));
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
     V.p = W.sl_p;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         __syncthreads();
         RS_STAMP(3);
         const int nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        if (!mono && (MODE == 0 || (MODE == 1 && A.single_round))) {
+        if (!mono && MODE == 0) {
             // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
             if (V.label != W.sl_label)
                 for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
@@ -457,8 +457,10 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         cnt->n_clusters += (unsigned long long)sh.nclusters;
         cnt->n_rounds += (unsigned long long)rounds;
         if (ok) {
-            cnt->n_pp += (unsigned long long)sh.nhits;
-            cnt->n_fp_errors += (unsigned long long)sh.nfp;
+            if (A.count_pp) {           // (multi-GPU: every rank resolves every collision, one of them counts)
+                cnt->n_pp += (unsigned long long)sh.nhits;
+                cnt->n_fp_errors += (unsigned long long)sh.nfp;
+            }
         } else {
             cnt->flags |= 4ULL;
         }
@@ -590,26 +592,6 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     }
 }
 
-// ---- multi-GPU helpers ------------------------------------------------------------------------------------------------------
-// candidate state table from the particle arrays (single GPU: the detect kernel gathers inline)
-__global__ __launch_bounds__(256) void k_gather_cst(rs_args A)
-{
-    const amc_resolve_ws &W = A.W;
-    const int ncand = min((int)A.O.cnt->cand_count, W.max_cand);
-    const size_t m = (size_t)W.max_cand;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < ncand; k += gridDim.x * blockDim.x) {
-        const int pp[2] = {W.cand_j[k], W.cand_i[k]};
-        for (int w = 0; w < 2; w++) {
-            const int p = pp[w];
-            double *t = W.cst + (size_t)(11 * w) * m + k;
-            t[0 * m] = A.S.x[p]; t[1 * m] = A.S.y[p]; t[2 * m] = A.S.z[p];
-            t[3 * m] = A.S.vx[p]; t[4 * m] = A.S.vy[p]; t[5 * m] = A.S.vz[p];
-            t[6 * m] = A.S.d[p]; t[7 * m] = A.S.dx[p]; t[8 * m] = A.S.dy[p]; t[9 * m] = A.S.dz[p];
-            t[10 * m] = A.S.flag[p] ? 1.0 : 0.0;
-        }
-    }
-}
-
 template <int GEOM>
 static void rs_launch_all(amc_ctx *c, const rs_args &A)
 {
@@ -650,8 +632,6 @@ static rs_args rs_make_args(amc_ctx *c)
     rs_args A;
     A.P = c->P; A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
     A.dbg = c->d_dbg;
-    A.single_round = 0;
-    A.allow_mono = 1;
     A.force_mono = 0;
     A.host_ncand = c->d_host_ncand;
     A.defer_commit = 0;
@@ -682,45 +662,6 @@ hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit)
     case AMC_GEOM_CUBE: rs_launch_all<AMC_GEOM_CUBE>(c, A); break;
     default: rs_launch_all<AMC_GEOM_PORE>(c, A); break;
     }
-    amc_prof_end(c);
-    return hipGetLastError();
-}
-
-// multi-GPU: one round (first: claim + round 1, else one continuation round), then the wide validation
-template <int GEOM>
-static void rs_launch_round(amc_ctx *c, rs_args A, int first)
-{
-    A.allow_mono = 0;           // the host drives the rounds (state exchange between them)
-    if (first) {
-        hipLaunchKernelGGL(k_gather_cst, dim3(64), dim3(256), 0, c->stream, A);
-        if (c->plan_split) {            // large sweep: the isolated pairs first, on the whole chip (same plan as single-GPU)
-            A.wide_plan = 1;
-            hipLaunchKernelGGL((k_pairs_wide<GEOM>), dim3(64), dim3(256), 0, c->stream, A);
-        }
-        hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, A);
-        A.wide_plan = 0;
-    } else {
-        A.single_round = 1;
-        hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);
-    }
-    hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
-}
-hipError_t amc_launch_resolve_round(amc_ctx *c, int first)
-{
-    const rs_args A = rs_make_args(c);
-    amc_prof_begin(c, AMC_K_RESOLVE);
-    switch (c->P.geometry) {
-    case AMC_GEOM_CUBE: rs_launch_round<AMC_GEOM_CUBE>(c, A, first); break;
-    default: rs_launch_round<AMC_GEOM_PORE>(c, A, first); break;
-    }
-    amc_prof_end(c);
-    return hipGetLastError();
-}
-hipError_t amc_launch_commit(amc_ctx *c)
-{
-    const rs_args A = rs_make_args(c);
-    amc_prof_begin(c, AMC_K_RESOLVE);
-    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
     amc_prof_end(c);
     return hipGetLastError();
 }

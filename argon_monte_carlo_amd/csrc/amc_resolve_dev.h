@@ -19,10 +19,8 @@ struct rs_args {
     amc_out O;
     long long n;
     int allpairs;
-    int single_round;         // multi-GPU: a continuation launch runs exactly one round and hands back to the host
     int defer_commit;         // leave the results in the slot arrays: the next streaming pass (or k_apply) writes them
     int apply_only;           // k_commit: only write deferred results (amc_flush)
-    int allow_mono;           // small sweeps may run validation + commit inside resolve_A
     int force_mono;           // the host launched ONLY this kernel (it expects a small sweep): do everything here
     int *host_ncand;          // host-mapped word: candidate count of this sweep, read (lagging) by the host to pick the launch plan (saves three kernels' latency)
     int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)

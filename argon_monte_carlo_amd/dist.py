@@ -1,13 +1,11 @@
 """Multi-GPU driver: one process per GPU, particles sharded by contiguous index range.
 
-Per step every rank advances only its shard (drift + walls + bounds), all-gathers the positions over RCCL/xGMI, detects
-the close pairs of the WHOLE system (same candidate set everywhere) and runs the identical ordered resolve on them, so
-cross-shard collisions and chains need no locking and no ownership logic inside the kernels.  The state (velocities,
-path accumulators, flag) of candidate particles owned by other ranks is exchanged on demand in a small table, by a
-integer SUM all-reduce of its int64 view (every entry is non-zero on exactly one rank, so the sum reproduces the
-owner's bits exactly, including -0.0 and NaN payloads; RCCL has no bitwise reductions).  If validation pulls further particles into a cluster, their rows are exchanged the same way
-before the next round.  The only data-path collectives are the position all-gather (24 B/particle/step) and those
-tables (a few hundred rows).
+Per step every rank advances only its shard (drift + walls + bounds), then ONE all-gather over RCCL/xGMI hands the
+positions and velocities of every shard to everybody (48 B per particle), and every rank runs the p-p sweep of the whole
+system exactly as a single GPU would (bin, detect, ordered resolve, commit).  All ranks compute every collision from
+identical inputs, so cross-shard pairs and chains need no locking, no ownership logic inside the kernels and no further
+exchange: the path accumulators and the flag of a particle only feed its own bookkeeping and are meaningful on its owner
+alone, which is also the rank that emits the particle's completed paths.  Nothing in the step waits for the host.
 
 ``ShardedSimulation`` only needs an *engine* with the ``mg_*`` methods of ``engine.ShardEngine`` and a communicator;
 tests/test_dist_gloo.py drives it with a NumPy engine over gloo on CPU.
@@ -34,36 +32,14 @@ class TorchComm:
         self.dist, self.rank, self.world, self.group = dist, rank, world, group
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         # world == 1 normally skips the collectives; AMC_DIST_NOSHORTCUT=1 issues them anyway (single-GPU rehearsal
-        # of the RCCL code path: tensor aliasing, in-place all-gather, int64 all-reduce)
+        # of the RCCL code path: tensors aliasing library memory, all-gather)
         self.shortcut = not (os.environ.get("AMC_DIST_NOSHORTCUT") == "1" and dist.is_initialized())
 
     def _stage(self, t):
         return t.is_cuda and self.backend != "nccl"
 
-    def allgather_inplace(self, full, n, world):
-        """full[lo:hi] of every rank -> full on every rank."""
-        if self.world == 1 and self.shortcut:
-            return
-        import torch
-        ranges = [shard_range(n, r, world) for r in range(world)]
-        lo, hi = ranges[self.rank]
-        equal = len({b - a for a, b in ranges}) == 1
-        if self._stage(full) or (not equal and self.backend != "nccl"):
-            parts = self.gather_shards(full[lo:hi].cpu(), ranges)
-            for (a, b), p in zip(ranges, parts):
-                if a != lo:
-                    full[a:b].copy_(p)
-        elif equal:
-            self.dist.all_gather_into_tensor(full, full[lo:hi], group=self.group)
-        else:
-            for r, (a, b) in enumerate(ranges):
-                self.dist.broadcast(full[a:b], src=r, group=self.group)
-
     def allgather_packed(self, send, recv):
         """recv = concatenation of every rank's `send` (equal sizes), in rank order."""
-        if self.world == 1 and self.shortcut:
-            recv.copy_(send)
-            return
         if self._stage(send):
             import torch
             h = send.cpu()
@@ -83,16 +59,6 @@ class TorchComm:
         parts = [torch.empty(m, dtype=mine.dtype, device=dev) for _ in ranges]
         self.dist.all_gather(parts, pad, group=self.group)
         return [p[:b - a].cpu() for (a, b), p in zip(ranges, parts)]
-
-    def allreduce_bits(self, t):
-        if (self.world == 1 and self.shortcut) or t.numel() == 0:
-            return
-        if self._stage(t):
-            h = t.cpu()
-            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
-            t.copy_(h)
-        else:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def allreduce_sum_ints(self, values):
         import torch
@@ -120,10 +86,6 @@ class TorchComm:
         parts = self.gather_shards(torch.from_numpy(rows.reshape(-1)), ranges)
         return [p.numpy().reshape(-1, width) for p in parts]
 
-    def allgather_rows(self, t_full, n, world):
-        """all-gather of an arbitrary per-particle tensor (used by download(), not on the hot path)."""
-        self.allgather_inplace(t_full, n, world)
-
 
 class ShardedSimulation:
     SUM_KEYS = ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors")
@@ -143,67 +105,28 @@ class ShardedSimulation:
             engine.set_stream(stream_ptr)
         self.engine = engine
         self.comm = comm if comm is not None else TorchComm(rank, world)
-        self.max_rounds = 64
 
     def upload(self, *arrays, **kw):
         """Every rank uploads the full initial state (only its shard of the non-position arrays is ever used)."""
         self.engine.upload(*arrays, **kw)
 
     # ---- one step -------------------------------------------------------------------------------------------------------
-    def _exchange_state(self, particles):
-        """Rows of `particles` (ascending, identical on every rank) from their owners to everybody."""
-        e = self.engine
-        if hasattr(e, "mg_exchange_begin"):          # list built / uploaded once inside the library
-            n = e.mg_exchange_begin(particles)
-            if n:
-                self.comm.allreduce_bits(e.exchange_tensor(n))
-                e.mg_exchange_end()
-            return
-        if len(particles) == 0:
-            return
-        e.mg_pack(particles)
-        self.comm.allreduce_bits(e.exchange_tensor(len(particles)))
-        e.mg_unpack(particles)
-
     def timestep(self, dt, reduce_stats=True, want_stats=True):
         self.engine.mg_local(dt)
         return self._sweep(reduce_stats, want_stats)
 
     def _sweep(self, reduce_stats=True, want_stats=True):
-        """positions of all shards -> everybody, detection on the whole system, ordered resolve, per-step counters"""
+        """positions + velocities of all shards -> everybody, then the sweep of the whole system on every rank"""
         e = self.engine
-        if hasattr(e, "mg_pack_positions") and hasattr(self.comm, "allgather_packed"):
-            if not (self.world == 1 and self.comm.shortcut):
-                send, recv = e.packed_positions(self.world)          # one collective for x, y and z
-                e.mg_pack_positions(self.world)
-                self.comm.allgather_packed(send, recv)
-                e.mg_unpack_positions(self.world, self.rank)
-        else:
-            for t in e.position_tensors():
-                self.comm.allgather_inplace(t, self.n, self.world)
-        ncand = e.mg_detect()
-        rounds = 0
-        if ncand:
-            if hasattr(e, "mg_exchange_begin"):
-                self._exchange_state(None)                           # endpoints of the candidates, canonical order
-            else:
-                ci, cj = e.mg_candidates(ncand)
-                known = np.unique(np.concatenate([ci, cj]))          # canonical order: ascending particle index
-                self._exchange_state(known)
-            dirty, new = e.mg_resolve_round(True)
-            rounds = 1
-            while dirty:
-                if rounds >= self.max_rounds:
-                    raise RuntimeError("resolve did not converge")
-                self._exchange_state(new)
-                dirty, new = e.mg_resolve_round(False)
-                rounds += 1
-            e.mg_commit()
+        if not (self.world == 1 and self.comm.shortcut):
+            send, recv = e.exchange_buffers(self.world)
+            e.mg_pack(self.world)
+            self.comm.allgather_packed(send, recv)
+        e.mg_sweep(self.world, self.rank)
         st = e.mg_finish(want_stats)
         if st is None:
             return None
-        st["n_rounds"] = rounds
-        if reduce_stats and (self.world > 1 or not getattr(self.comm, 'shortcut', True)):
+        if reduce_stats and (self.world > 1 or not self.comm.shortcut):
             tot = self.comm.allreduce_sum_ints([st[k] for k in self.SUM_KEYS])
             st.update(dict(zip(self.SUM_KEYS, tot)))
         return st

@@ -165,16 +165,12 @@ class Engine:
 
 class ShardEngine(Engine):
     """Engine + the multi-GPU entry points (include/argonmc.h, "multi-GPU"): the object dist.ShardedSimulation drives.
-    Positions and the exchange table are exposed as torch tensors that alias the library's device memory."""
+    The buffers of the per-step all-gather are exposed as torch tensors that alias the library's device memory."""
 
     def __init__(self, params, lo, hi):
         super().__init__(params)
-        from ._abi import AmcDeviceView
         self.lo, self.hi = int(lo), int(hi)
         self._ck(self.lib.amc_set_shard(self._ctx, self.lo, self.hi))
-        self._view = AmcDeviceView()
-        self._ck(self.lib.amc_device_view_get(self._ctx, C.byref(self._view)))
-        self._i32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
 
     @staticmethod
     def _wrap(ptr, count, typestr):
@@ -186,79 +182,24 @@ class ShardEngine(Engine):
         d.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
         return torch.as_tensor(d, device="cuda")
 
-    def position_tensors(self):
-        if not hasattr(self, "_pos_t"):
-            v = self._view
-            self._pos_t = [self._wrap(p, self.n, "<f8") for p in (v.x, v.y, v.z)]
-        return self._pos_t
-
-    def exchange_tensor(self, n_particles):
-        """int64 view of the state table rows in use: [11 * n_particles]."""
-        if not hasattr(self, "_xchg_t"):
-            self._xchg_t = self._wrap(self._view.xchg, 11 * int(self._view.xchg_capacity), "<i8")
-        return self._xchg_t[: 11 * int(n_particles)]
-
-    def packed_positions(self, world):
-        """(send, recv) tensors of the packed position exchange: float64[3*m] and float64[world*3*m]."""
-        if getattr(self, "_pp_world", None) != world:
+    def exchange_buffers(self, world):
+        """(send, recv) tensors of the all-gather: float64[6*m] (x|y|z|vx|vy|vz of the shard) and float64[world*6*m]."""
+        if getattr(self, "_xb_world", None) != world:
             send, recv, m = C.c_void_p(), C.c_void_p(), C.c_int64(0)
-            self._ck(self.lib.amc_mg_positions_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(m)))
+            self._ck(self.lib.amc_mg_exchange_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(m)))
             mm = max(1, m.value)
-            self._pp = (self._wrap(send.value, 3 * mm, "<f8"), self._wrap(recv.value, 3 * mm * world, "<f8"))
-            self._pp_world = world
-        return self._pp
-
-    def mg_pack_positions(self, world):
-        self._ck(self.lib.amc_mg_pack_positions(self._ctx, int(world)))
-
-    def mg_unpack_positions(self, world, rank):
-        self._ck(self.lib.amc_mg_unpack_positions(self._ctx, int(world), int(rank)))
+            self._xb = (self._wrap(send.value, 6 * mm, "<f8"), self._wrap(recv.value, 6 * mm * world, "<f8"))
+            self._xb_world = world
+        return self._xb
 
     def mg_local(self, dt):
         self._ck(self.lib.amc_mg_local(self._ctx, float(dt)))
 
-    def mg_detect(self):
-        n = C.c_int64(0)
-        self._ck(self.lib.amc_mg_detect(self._ctx, C.byref(n)))
-        return n.value
+    def mg_pack(self, world):
+        self._ck(self.lib.amc_mg_pack(self._ctx, int(world)))
 
-    def mg_candidates(self, ncand):
-        ci = np.empty(max(1, ncand), dtype=np.int32)
-        cj = np.empty(max(1, ncand), dtype=np.int32)
-        got = C.c_size_t(0)
-        self._ck(self.lib.amc_mg_candidates(self._ctx, self._i32(ci), self._i32(cj), len(ci), C.byref(got)))
-        return ci[:got.value], cj[:got.value]
-
-    def mg_pack(self, particles):
-        p = np.ascontiguousarray(particles, dtype=np.int32)
-        self._ck(self.lib.amc_mg_pack_state(self._ctx, self._i32(p), len(p)))
-
-    def mg_exchange_begin(self, particles=None):
-        """Pack this rank's rows of the exchange list (None: the endpoints of the detected candidates); returns the rows."""
-        n = C.c_size_t(0)
-        if particles is None:
-            self._ck(self.lib.amc_mg_exchange_begin(self._ctx, None, 0, C.byref(n)))
-        else:
-            p = np.ascontiguousarray(particles, dtype=np.int32)
-            self._ck(self.lib.amc_mg_exchange_begin(self._ctx, self._i32(p), len(p), C.byref(n)))
-        return n.value
-
-    def mg_exchange_end(self):
-        self._ck(self.lib.amc_mg_exchange_end(self._ctx))
-
-    def mg_unpack(self, particles):
-        p = np.ascontiguousarray(particles, dtype=np.int32)
-        self._ck(self.lib.amc_mg_unpack_state(self._ctx, self._i32(p), len(p)))
-
-    def mg_resolve_round(self, first):
-        dirty = C.c_int(0)
-        buf = np.empty(max(1024, self.n // 64), dtype=np.int32)
-        got = C.c_size_t(0)
-        self._ck(self.lib.amc_mg_resolve_round(self._ctx, int(first), C.byref(dirty), self._i32(buf), len(buf), C.byref(got)))
-        return bool(dirty.value), buf[:got.value].copy()
-
-    def mg_commit(self):
-        self._ck(self.lib.amc_mg_commit(self._ctx))
+    def mg_sweep(self, world, rank):
+        self._ck(self.lib.amc_mg_sweep(self._ctx, int(world), int(rank)))
 
     def mg_finish(self, want_stats=True):
         if not want_stats:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AMC_ABI_VERSION 1
+#define AMC_ABI_VERSION 2
 
 typedef enum amc_status {
     AMC_OK = 0,
@@ -249,54 +249,34 @@ int amc_temp_device_draws(amc_ctx *ctx, int case_id, int32_t *idx, double *norma
                           double *surface_energy, size_t cap, size_t *n);
 
 /* ---- multi-GPU (one process per GPU; particles sharded by index range) ------------------------------
- * Every rank allocates all n particles but advances only its shard [lo, hi).  Per step (argon_monte_carlo_amd/dist.py):
+ * Every rank allocates all n particles but advances only its shard [lo, hi); the reference has no counterpart (its
+ * parallelism is multiprocessing.Pool over cells, Pore:404-406, 546).  Per step (argon_monte_carlo_amd/dist.py):
  *   amc_mg_local            drift + walls + bounds on [lo,hi)                       (Pore:426-512 on the shard)
- *   <all-gather x,y,z>      RCCL, in place on the pointers of amc_device_view
- *   amc_mg_detect           bin ALL n particles + close-pair detection -> the same candidate SET on every rank
- *   amc_mg_candidates       the pairs, for the host to build the canonical (sorted) list of particles to exchange
- *   amc_mg_pack_state       rows of the owned particles of that list into the exchange table (zeros elsewhere)
- *   <all-reduce SUM/int64>  integer sum over the int64 view of the table (one non-zero contributor per entry): exact,
- *                           keeps -0.0 and NaN payloads
- *   amc_mg_unpack_state     table rows -> local arrays of the non-owned particles of the list
- *   amc_mg_resolve_round    one round of the ordered resolve + wide validation; returns whether clusters merged and
- *                           which not-yet-exchanged particles were pulled in (their state is exchanged the same way
- *                           before the next round, so every rank emulates every cluster on identical inputs)
- *   amc_mg_commit           results -> particle arrays (every rank applies all of them; owners stay authoritative)
+ *   amc_mg_pack             x|y|z|vx|vy|vz of the shard -> send buffer
+ *   <all-gather>            RCCL over xGMI: send of every rank -> recv (48 B per particle and step)
+ *   amc_mg_sweep            recv -> position and velocity arrays of the other shards, then the p-p sweep of the WHOLE
+ *                           system exactly as on one GPU (bin all n, detect, ordered resolve, commit): every rank
+ *                           computes every collision from identical positions and velocities, so cross-shard pairs
+ *                           and chains need no further exchange.  The path accumulators and the flag of a particle
+ *                           matter only to its own bookkeeping: they are meaningful on the owner alone, which is
+ *                           also the one that emits the particle's completed paths; the collision count is reported
+ *                           by the rank that owns particle 0.
  *   amc_mg_finish           bounds check after the sweep on [lo,hi), step counter, per-step counters
- * Energised walls (Temp:662-853) shard the same way: amc_temp_begin / amc_wall_hits / amc_wall_apply act on [lo,hi);
- * the host concatenates the hits of all ranks in rank order (= ascending particle index) before drawing the random
- * directions, so every rank consumes the two RNG streams identically.  amc_mg_bounds is the bounds
- * check between the walls and the sweep (Temp:804) on [lo,hi) without a counter read-back; the sweep then runs as above.
- * No data-path collective other than the position all-gather and the small state tables. */
+ * Nothing in the step waits for the host.  Energised walls (Temp:662-853) shard the same way: amc_temp_begin /
+ * amc_wall_hits / amc_wall_apply act on [lo,hi); the host concatenates the hits of all ranks in rank order (=
+ * ascending particle index) before drawing the random directions, so every rank consumes the two RNG streams
+ * identically.  amc_mg_bounds is the bounds check between the walls and the sweep (Temp:804) on [lo,hi)
+ * without a counter read-back; the sweep then runs as above. */
 int amc_set_shard(amc_ctx *ctx, int64_t lo, int64_t hi);
-typedef struct amc_device_view {
-    void *x, *y, *z;              /* float64[n] each: the position arrays themselves (all-gathered in place)      */
-    void *xchg;                   /* exchange table, float64[11][xchg_capacity] (row-major), also viewed as int64 */
-    int64_t xchg_capacity;        /* particles per exchange                                                      */
-    int64_t n, lo, hi;
-} amc_device_view;
-int amc_device_view_get(amc_ctx *ctx, amc_device_view *out);
 int amc_mg_local(amc_ctx *ctx, double dt);
-/* Packed form of the position all-gather (one collective per step instead of three).  With m = ceil(n / world):
- * send = float64[3][m], this rank's x|y|z shard (zero padded); recv = float64[world][3][m], the send blocks of all
- * ranks in rank order (the output of an all-gather of `send`).  Shards follow the driver's rule: rank r owns
- * base + (r < n % world) particles starting at r * base + min(r, n % world), base = n / world. */
-int amc_mg_positions_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *m);
-int amc_mg_pack_positions(amc_ctx *ctx, int world);
-int amc_mg_unpack_positions(amc_ctx *ctx, int world, int rank);
-int amc_mg_detect(amc_ctx *ctx, int64_t *n_candidates);
-int amc_mg_candidates(amc_ctx *ctx, int32_t *cand_i, int32_t *cand_j, size_t cap, size_t *n);
-int amc_mg_pack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
-/* the same exchange in two calls around the all-reduce, with the list built and uploaded once: `particles` == NULL takes
- * the sorted set of endpoints of the candidates amc_mg_detect found (identical on every rank), otherwise the given
- * ascending list (new cluster members); *n_rows = rows to reduce.  amc_mg_exchange_end unpacks the reduced table. */
-int amc_mg_exchange_begin(amc_ctx *ctx, const int32_t *particles, size_t n, size_t *n_rows);
-int amc_mg_exchange_end(amc_ctx *ctx);
-int amc_mg_unpack_state(amc_ctx *ctx, const int32_t *particles, size_t n);
-/* first != 0: start the sweep (claim slots, round 1); else continue with the next round.  *dirty = clusters merged
- * (another round is needed); new_members receives the particles pulled in by validation (ascending). */
-int amc_mg_resolve_round(amc_ctx *ctx, int first, int *dirty, int32_t *new_members, size_t cap, size_t *n_new);
-int amc_mg_commit(amc_ctx *ctx);
+/* Buffers of the all-gather.  With m = ceil(n / world): send = float64[6][m], this rank's x|y|z|vx|vy|vz shard (zero
+ * padded); recv = float64[world][6][m], the send blocks of all ranks in rank order (the output of an all-gather of
+ * `send`).  Shards follow the driver's rule: rank r owns base + (r < n % world) particles starting at
+ * r * base + min(r, n % world), base = n / world.  The pointers stay valid until the context is destroyed or the
+ * function is called with another world size. */
+int amc_mg_exchange_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *m);
+int amc_mg_pack(amc_ctx *ctx, int world);
+int amc_mg_sweep(amc_ctx *ctx, int world, int rank);       /* world == 1: no unpack (nothing was exchanged) */
 int amc_mg_bounds(amc_ctx *ctx);
 int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no host synchronisation (counters stay on the device) */
 

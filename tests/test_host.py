@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from argon_monte_carlo_amd import _lib, outputs as OUT, params as PR
-from argon_monte_carlo_amd._abi import AmcParams
+from argon_monte_carlo_amd._abi import AMC_ABI_VERSION, AmcParams
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.amc_abi_version() == 1
+    assert lib.amc_abi_version() == AMC_ABI_VERSION == 2
 
 
 def test_no_cpu_fallback_without_gpu():

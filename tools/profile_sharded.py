@@ -39,20 +39,10 @@ steps = 200
 t_all = time.perf_counter()
 for s in range(steps):
     timed("mg_local", e.mg_local, c["dt"])
-    send, recv = e.packed_positions(sim.world)
-    timed("pos_pack", e.mg_pack_positions, sim.world)
+    send, recv = e.exchange_buffers(sim.world)
+    timed("pack", e.mg_pack, sim.world)
     timed("allgather", sim.comm.allgather_packed, send, recv)
-    timed("pos_unpack", e.mg_unpack_positions, sim.world, sim.rank)
-    ncand = timed("mg_detect", e.mg_detect)
-    if ncand:
-        nrows = timed("x_begin", e.mg_exchange_begin, None)
-        timed("x_allreduce", sim.comm.allreduce_bits, e.exchange_tensor(nrows))
-        timed("x_end", e.mg_exchange_end)
-        dirty, new = timed("round1", e.mg_resolve_round, True)
-        while dirty:
-            timed("exchange2", sim._exchange_state, new)
-            dirty, new = timed("roundN", e.mg_resolve_round, False)
-        timed("commit", e.mg_commit)
+    timed("sweep", e.mg_sweep, sim.world, sim.rank)
     timed("finish", e.mg_finish, False)
 torch.cuda.synchronize()
 tot = time.perf_counter() - t_all
