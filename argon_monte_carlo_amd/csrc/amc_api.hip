@@ -221,7 +221,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
-    c->kin_send = c->kin_recv = nullptr; c->kin_world = 0; c->kin_m = 0;
+    c->kin_send = c->kin_recv = nullptr; c->kin_world = 0; c->kin_m = 0; c->kin_lists = false;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
     c->stream = nullptr;

@@ -73,11 +73,15 @@ int amc_mg_sweep(amc_ctx *c, int world, int rank)
     if (world > 1) {
         int rc = mg_check_shard(c, world, rank);
         if (rc) return rc;
+        if (!c->kin_lists) return amc_fail(c, AMC_ERR_STATE, "amc_mg_sweep(world=%d) without amc_mg_pack in this step", world);
         AMC_HIP(c, amc_launch_kin_pack(c, world, rank, 1));
     }
-    // the single-GPU sweep over all n particles; results are written by the commit of the sweep itself (the next
-    // streaming pass covers only the shard, so nothing is deferred to it)
-    return amc_enqueue_sweep(c, false, false);
+    // the single-GPU sweep over all n particles; the per-cell lists were built by the pack / unpack kernels (if nothing
+    // was packed — one rank, no exchange — they are built here).  Results are written by the commit of the sweep itself
+    // (the next streaming pass covers only the shard, so nothing is deferred to it).
+    const bool lists = c->kin_lists;
+    c->kin_lists = false;
+    return amc_enqueue_sweep(c, lists, false);
 }
 
 int amc_mg_bounds(amc_ctx *c)

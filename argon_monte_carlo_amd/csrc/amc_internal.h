@@ -151,6 +151,7 @@ struct amc_ctx {
     double *kin_send, *kin_recv;   // packed exchange of positions and velocities: [6][m] and [world][6][m]
     int kin_world;
     int64_t kin_m;
+    bool kin_lists;                // amc_mg_pack started this step's per-cell lists (the unpack completes them)
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);

@@ -252,10 +252,11 @@ int amc_temp_device_draws(amc_ctx *ctx, int case_id, int32_t *idx, double *norma
  * Every rank allocates all n particles but advances only its shard [lo, hi); the reference has no counterpart (its
  * parallelism is multiprocessing.Pool over cells, Pore:404-406, 546).  Per step (argon_monte_carlo_amd/dist.py):
  *   amc_mg_local            drift + walls + bounds on [lo,hi)                       (Pore:426-512 on the shard)
- *   amc_mg_pack             x|y|z|vx|vy|vz of the shard -> send buffer
+ *   amc_mg_pack             x|y|z|vx|vy|vz of the shard -> send buffer (and the shard's particles into the per-cell
+ *                           lists of the detection grid: the pack and unpack kernels see every final position once)
  *   <all-gather>            RCCL over xGMI: send of every rank -> recv (48 B per particle and step)
- *   amc_mg_sweep            recv -> position and velocity arrays of the other shards, then the p-p sweep of the WHOLE
- *                           system exactly as on one GPU (bin all n, detect, ordered resolve, commit): every rank
+ *   amc_mg_sweep            recv -> position and velocity arrays (and per-cell lists) of the other shards, then the
+ *                           p-p sweep of the WHOLE system exactly as on one GPU (detect, ordered resolve, commit): every rank
  *                           computes every collision from identical positions and velocities, so cross-shard pairs
  *                           and chains need no further exchange.  The path accumulators and the flag of a particle
  *                           matter only to its own bookkeeping: they are meaningful on the owner alone, which is
