@@ -249,7 +249,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
     if (c->sweep_epoch == 0u) c->sweep_epoch = 1u;      // (0 is the value of the zero-initialised table)
     // launch plan of this sweep from the candidate count of the most recent sweep the host has seen (a word the resolve
     // kernel writes into host-mapped memory; it may lag by a step): only the large plan uses the degrees
-    c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= AMC_PLAN_SMALL);
+    c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
     D.deg = c->plan_split ? c->W.deg : nullptr; D.epoch = c->sweep_epoch;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {

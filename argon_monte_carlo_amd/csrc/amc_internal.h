@@ -145,6 +145,7 @@ struct amc_ctx {
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
     unsigned int sweep_epoch;      // tag of the degree counts of the current sweep (advanced by every detect launch)
     bool plan_split;               // launch plan of the current sweep, fixed when its detect kernel is launched
+    int plan_small;                // candidate pairs up to which the single resolve kernel does the whole sweep
     // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
     char *h_pin;
     size_t h_pin_bytes;
@@ -169,7 +170,8 @@ void amc_prof_cancel(amc_ctx *c);
 void amc_prof_collect(amc_ctx *c);
 
 // stage bits of the streaming kernel
-#define AMC_PLAN_SMALL 640      // candidate pairs up to which the single resolve kernel does the whole sweep (RS_SMALL)
+#define AMC_PLAN_SMALL 430      // default of amc_ctx::plan_small: measured crossover of the two launch plans (tools/plan_sweep.sh;
+                                // experiments: environment variable AMC_PLAN_SMALL)
 #define AMC_ST_DRIFT 1
 #define AMC_ST_WALLS 2
 #define AMC_ST_BOUNDS 4

@@ -24,7 +24,7 @@
 // The ordered logic runs in ONE 512-thread workgroup (phases separated by __syncthreads, counters in LDS): the data
 // set is a few hundred pairs, so the cost is latency, not throughput.  Everything that is scattered memory traffic
 // is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and for
-// large sweeps (> 640 candidates) the isolated pairs are emulated by a wide kernel first (k_pairs_wide), the first
+// large sweeps (> 430 candidates) the isolated pairs are emulated by a wide kernel first (k_pairs_wide), the first
 // round's validation probes and the commit scatter are separate wide kernels, and only the entangled remainder and
 // the later rounds stay in the workgroup.  A multi-particle cluster is emulated by a whole wave (rs_emulate_coop).
 #include "amc_resolve_dev.h"
@@ -40,7 +40,6 @@
 
 #define RS_NS 6144             // slot labels / sizes / dirty flags kept in LDS (54 KB)
 #define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
-#define RS_SMALL AMC_PLAN_SMALL // candidate pairs up to which resolve_A does everything itself
 
 // MODE 0: first round only (claim, label, emulate), validation + commit are the wide kernels that follow
 // MODE 1: continuation: if the wide validation found merges, run the remaining rounds (validation in-kernel)
@@ -102,7 +101,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     // MODE 2 always, MODE 0 for small sweeps: validation and commit in this kernel (the wide kernels then find
     // ctl.active == 0 and exit); large sweeps hand over after the first round
-    const bool mono = (MODE == 2) || (MODE == 0 && (A.force_mono || ncand <= RS_SMALL));
+    const bool mono = (MODE == 2) || (MODE == 0 && (A.force_mono || ncand <= A.plan_small));
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
     V.p = W.sl_p;
@@ -634,6 +633,7 @@ static rs_args rs_make_args(amc_ctx *c)
     A.dbg = c->d_dbg;
     A.force_mono = 0;
     A.host_ncand = c->d_host_ncand;
+    A.plan_small = c->plan_small;
     A.defer_commit = 0;
     A.apply_only = 0;
     A.sweep_epoch = c->sweep_epoch;

@@ -22,6 +22,7 @@ struct rs_args {
     int defer_commit;         // leave the results in the slot arrays: the next streaming pass (or k_apply) writes them
     int apply_only;           // k_commit: only write deferred results (amc_flush)
     int force_mono;           // the host launched ONLY this kernel (it expects a small sweep): do everything here
+    int plan_small;           // candidate pairs up to which the first resolve kernel does the whole sweep itself
     int *host_ncand;          // host-mapped word: candidate count of this sweep, read (lagging) by the host to pick the launch plan (saves three kernels' latency)
     int count_pp;             // this rank adds the sweep's collision count to the counters (rank 0 in multi-GPU)
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle

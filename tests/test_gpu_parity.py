@@ -781,7 +781,7 @@ def test_tolerated_fp_events_match_oracle(Engine, O):
 # ---------------------------------------------------------------------------------------------- large-sweep launch plan
 @pytest.mark.parametrize("kind,n", [("cube", 400_000), ("pore", 1_000_000)])
 def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
-    """Sweeps with more than 640 candidates take the large plan: isolated pairs in k_pairs_wide, the entangled rest in
+    """Sweeps with more than 430 candidates take the large plan: isolated pairs in k_pairs_wide, the entangled rest in
     the ordered workgroup, wide validation, continuation, wide commit.  State and counters equal the oracle's bit for
     bit at every step, and the profile shows that the wide pair kernel really ran."""
     if kind == "cube":
