@@ -15,7 +15,6 @@ int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
 int amc_mg_local(amc_ctx *c, double dt)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;
-    { int rc_ = amc_flush(c); if (rc_) return rc_; }
     if (c->allpairs || c->P.geometry == AMC_GEOM_CELL || c->P.geometry == AMC_GEOM_PORE_ENERGISED)
         return amc_fail(c, AMC_ERR_INVALID, "amc_mg_local needs the binned detector and the cube / specular pore geometry (energised walls: amc_temp_begin)");
     AMC_HIP(c, hipSetDevice(c->device));
@@ -77,11 +76,12 @@ int amc_mg_sweep(amc_ctx *c, int world, int rank)
         AMC_HIP(c, amc_launch_kin_pack(c, world, rank, 1));
     }
     // the single-GPU sweep over all n particles; the per-cell lists were built by the pack / unpack kernels (if nothing
-    // was packed — one rank, no exchange — they are built here).  Results are written by the commit of the sweep itself
-    // (the next streaming pass covers only the shard, so nothing is deferred to it).
+    // was packed — one rank, no exchange — they are built here).  The scatter of the results is deferred as on one GPU:
+    // the next streaming pass over the shard picks up those of its own particles, the next unpack releases the slots of
+    // the others (whose results arrive from their owners).
     const bool lists = c->kin_lists;
     c->kin_lists = false;
-    return amc_enqueue_sweep(c, lists, false);
+    return amc_enqueue_sweep(c, lists, true);
 }
 
 int amc_mg_bounds(amc_ctx *c)

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_kin_pack(kin_arrays S, long long lo, lo
 }
 __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, int world, int rank, long long m,
                                                     const double *__restrict__ recv, amc_grid G, amc_lists B,
-                                                    amc_dev_counters *cnt)
+                                                    amc_dev_counters *cnt, int *__restrict__ slot_of)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)world * m) return;
@@ -46,6 +46,9 @@ __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, i
         v[e] = blk[e * m + u];
         S.a[e][lo + u] = v[e];
     }
+    // deferred commit of the previous sweep: this rank resolved the other shards' collisions too, but their results
+    // arrive with the owners' blocks — only the slot is released (own particles: the streaming pass took theirs)
+    if (slot_of[lo + u] >= 0) slot_of[lo + u] = -1;
     bool outside = false;
     amc_list_insert(G, B, (int)(lo + u), v[0], v[1], v[2], &outside);
     if (outside) atomicOr(&cnt->flags, 8ULL);
@@ -64,7 +67,7 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
                            (long long)c->hi, m, c->kin_send, c->G, c->B, c->d_cnt);
     } else {
         hipLaunchKernelGGL(k_kin_unpack, dim3((unsigned)(((long long)world * m + 255) / 256)), dim3(256), 0, c->stream, S,
-                           (long long)c->n, world, rank, m, c->kin_recv, c->G, c->B, c->d_cnt);
+                           (long long)c->n, world, rank, m, c->kin_recv, c->G, c->B, c->d_cnt, c->W.slot_of);
     }
     amc_prof_end(c);
     return hipGetLastError();

@@ -148,7 +148,7 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { build = 1; c->B.epoch++; }
     amc_lazy L;
     memset(&L, 0, sizeof L);
-    if (c->lazy_pending && c->lo == 0 && c->hi == c->n) {
+    if (c->lazy_pending) {              // (a shard: its own particles here, the slots of the others are cleared by the unpack)
         const amc_resolve_ws &W = c->W;
         L.slot_of = W.slot_of; L.x = W.sl_x; L.y = W.sl_y; L.z = W.sl_z; L.vx = W.sl_vx; L.vy = W.sl_vy; L.vz = W.sl_vz;
         L.d = W.sl_d; L.dx = W.sl_dx; L.dy = W.sl_dy; L.dz = W.sl_dz; L.flag = W.sl_flag; L.moved = W.sl_moved;
