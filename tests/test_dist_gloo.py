@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the multi-GPU driver argon_monte_carlo_amd.dist.ShardedSimulation.
+"""world_size-2 (and 3) gloo test (CPU) of the multi-GPU driver argon_monte_carlo_amd.dist.ShardedSimulation.
 
 The driver is exercised with a NumPy engine that implements the mg_* protocol with simple deterministic rules (not the
 physics — that is tested on the GPU against the oracle).  What a rank does not own and has not received is poisoned with
@@ -174,15 +174,15 @@ class _NoComm:
     def allreduce_sum_ints(self, v): return list(v)
 
 
-@pytest.mark.parametrize("n", [240, 251])       # equal and unequal shards
-def test_two_ranks_equal_one_rank(n):
+@pytest.mark.parametrize("n,world", [(240, 2), (251, 2), (251, 3)])       # equal and unequal shards
+def test_ranks_equal_one_rank(n, world):
     steps = 6
     ref_sim, ref_tot = run_sim(n, 0, 1, steps, _NoComm())
     ref = ref_sim.engine.download()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, steps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
     got, tot = q.get(timeout=120)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): the sharded path with 2 ranks on ONE MI355X (gloo, collectives staged through the host — RCCL refuses
+"""GPU (-m gpu): the sharded path with 2 (and 3) ranks on ONE MI355X (gloo, collectives staged through the host — RCCL refuses
 two ranks on one device) must equal the single-context engine bit for bit: state, counters and histograms."""
 import os
 import socket
@@ -51,8 +51,10 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("kind,n,steps", [("cube", 30000, 8), ("pore", 60001, 6), ("cube", 400000, 5)])      # equal / unequal shards; large-sweep plan
-def test_two_ranks_one_gpu_equal_single_engine(kind, n, steps):
+@pytest.mark.parametrize("kind,n,steps,world", [("cube", 30000, 8, 2), ("pore", 60001, 6, 2), ("cube", 400000, 5, 2),   # equal / unequal shards; large-sweep plan
+                                                ("cube", 200000, 40, 2), ("pore", 500001, 30, 2),   # longer runs: deferred commits, slot release
+                                                ("cube", 100003, 10, 3)])                           # three ranks, unequal shards
+def test_ranks_on_one_gpu_equal_single_engine(kind, n, steps, world):
     from argon_monte_carlo_amd.engine import Engine
     p, c, init = _case(kind, n)
     eng = Engine(p)
@@ -65,7 +67,7 @@ def test_two_ranks_one_gpu_equal_single_engine(kind, n, steps):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, n, steps, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, n, steps, q)) for r in range(world)]
     for pr in procs:
         pr.start()
     full, tot, counts, npaths = q.get(timeout=300)
