@@ -118,9 +118,9 @@ def _temp_worker(rank, world, port, n, steps, q):
         dist.destroy_process_group()
 
 
-def test_energised_walls_two_ranks_one_gpu_equal_single_engine():
+@pytest.mark.parametrize("n,steps", [(200000, 5), (4000000, 2)])      # the second: BASELINE configs[4] at its full size
+def test_energised_walls_two_ranks_one_gpu_equal_single_engine(n, steps):
     from argon_monte_carlo_amd.engine import EnergisedEngine
-    n, steps = 200000, 5
     p, c, init = _temp_case(n)
     eng = EnergisedEngine(p)
     eng.upload(*init)
@@ -138,7 +138,7 @@ def test_energised_walls_two_ranks_one_gpu_equal_single_engine():
     procs = [ctx.Process(target=_temp_worker, args=(r, 2, port, n, steps, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    full, rows = q.get(timeout=300)
+    full, rows = q.get(timeout=600)
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0

@@ -408,12 +408,14 @@ def test_pore_5e5_properties(Engine):
     eng.close()
 
 
-def test_temp_1e6_two_steps_vs_oracle(O):
-    """BASELINE config 4 (energised pore, N = 1,000,000): GPU == oracle bit for bit incl. the step's momentum/energy."""
+@pytest.mark.parametrize("n", [1_000_000, 4_000_000])
+def test_temp_two_steps_vs_oracle(O, n):
+    """BASELINE configs[3] / [4] (energised pore, N = 1,000,000 / 4,000,000, here on one GPU): GPU == oracle bit for bit
+    incl. the step's momentum/energy."""
     import random
     from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
     from argon_monte_carlo_amd.engine import EnergisedEngine
-    p, c = PR.pore_params(n=1_000_000, energised=True)
+    p, c = PR.pore_params(n=n, energised=True)
     p.reserved0 |= 1
     init = IC.pore_ic(p, c, seed=17)
     energies = SurfaceEnergies(c)
@@ -429,7 +431,7 @@ def test_temp_1e6_two_steps_vs_oracle(O):
         for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
             assert st[k] == so[k], (s, k, st, so)
         assert (m, ec, eh) == (m2, ec2, eh2) and st["n_wall"] > 100
-        assert_state_equal(eng.download(), orc.state(), ("temp1e6", s))
+        assert_state_equal(eng.download(), orc.state(), ("temp", n, s))
     eng.close()
 
 
