@@ -68,6 +68,12 @@ class AmcPathRecord(C.Structure):
                 ("which", C.c_int32), ("reserved", C.c_int32), ("total", _D), ("px", _D), ("py", _D), ("pz", _D)]
 
 
+class AmcIcConfig(C.Structure):
+    """amc_ic_config (include/argonmc.h): synthetic initial conditions generated on the device."""
+    _fields_ = [("struct_size", C.c_int32), ("n_regions", C.c_int32), ("seed", C.c_uint64), ("a_shape", C.c_double),
+                ("first", C.c_int64 * 9), ("radius", C.c_double * 8), ("z_lo", C.c_double * 8), ("z_hi", C.c_double * 8)]
+
+
 class AmcTempRng(C.Structure):
     """amc_temp_rng (include/argonmc.h): configuration of the opt-in device-side energised-wall sampling."""
     _fields_ = [("struct_size", C.c_int32), ("n_gl", C.c_int32), ("seed", C.c_uint64),

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 import subprocess
 
-from ._abi import (AMC_ABI_VERSION, AmcParams, AmcPathRecord, AmcStepStats, AmcTempRng)
+from ._abi import (AMC_ABI_VERSION, AmcIcConfig, AmcParams, AmcPathRecord, AmcStepStats, AmcTempRng)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libargonmc.so")
@@ -52,6 +52,7 @@ SIGNATURES = {
     "amc_paths_pending": (C.c_int, [_ctx, C.POINTER(C.c_size_t)]),
     "amc_histograms": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "amc_reset_outputs": (C.c_int, [_ctx]),
+    "amc_init_synthetic": (C.c_int, [_ctx, C.POINTER(AmcIcConfig)]),
     "amc_set_shard": (C.c_int, [_ctx, C.c_int64, C.c_int64]),
     "amc_mg_local": (C.c_int, [_ctx, C.c_double]),
     "amc_mg_exchange_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),

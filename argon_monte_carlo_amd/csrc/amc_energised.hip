@@ -11,6 +11,7 @@
 // The cases are sequential in the reference (each mask is evaluated after the previous handler ran), hence one
 // hits/apply pair per case.  Both kernels are O(N) streaming passes over positions (+prior); hits are ~1e-3 of N.
 #include "amc_internal.h"
+#include "amc_philox.h"
 
 struct temp_records {
     int *idx;
@@ -161,24 +162,6 @@ hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n)
 
 
 // ---- opt-in non-parity mode: directions and energies drawn on the device (include/argonmc.h, amc_temp_rng) -----------
-// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a hit's random numbers depend only on (seed, particle, step,
-// case, attempt) — not on the order the hits were found in, the shard layout or the launch geometry.
-__device__ inline void philox_round(unsigned int (&c)[4], const unsigned int (&k)[2])
-{
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
-    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k[0], n1 = (unsigned int)p1;
-    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k[1], n3 = (unsigned int)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-}
-__device__ inline void philox4x32_10(unsigned int (&c)[4], unsigned long long seed)
-{
-    unsigned int k[2] = {(unsigned int)seed, (unsigned int)(seed >> 32)};
-    for (int r = 0; r < 10; r++) {
-        philox_round(c, k);
-        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-    }
-}
-
 // surface_energy_gap (Temp:143-152): 9 T n k (T/theta)^3 * integral_0^{theta/T} x^3/(e^x - 1) dx, Gauss-Legendre
 __device__ inline double temp_gap_energy(const amc_temp_rng &g, double z)
 {

@@ -110,6 +110,11 @@ class ShardedSimulation:
         """Every rank uploads the full initial state (only its shard of the non-position arrays is ever used)."""
         self.engine.upload(*arrays, **kw)
 
+    def init_synthetic(self, cfg):
+        """Initial conditions generated on the device (``ic.device_ic_config``): a particle's numbers depend on the seed and
+        its index only, so every rank builds the identical system."""
+        self.engine.init_synthetic(cfg)
+
     # ---- one step -------------------------------------------------------------------------------------------------------
     def timestep(self, dt, reduce_stats=True, want_stats=True):
         self.engine.mg_local(dt)

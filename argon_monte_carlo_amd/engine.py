@@ -60,6 +60,10 @@ class Engine:
         self._ck(self.lib.amc_upload(self._ctx, *[_d(a) for a in arrs],
                                      None if f is None else f.ctypes.data_as(C.POINTER(C.c_uint8))))
 
+    def init_synthetic(self, cfg):
+        """Synthetic initial conditions generated on the device (``ic.device_ic_config``); replaces ``upload``."""
+        self._ck(self.lib.amc_init_synthetic(self._ctx, C.byref(cfg)))
+
     def download(self):
         n = self.n
         arrs = [np.empty(n) for _ in range(10)]

@@ -23,12 +23,11 @@ def cube_ic(p, consts, seed=127):
     return x, y, z, vx, vy, vz
 
 
-def pore_ic(p, consts, seed=17):
-    """Five stacked cylinders populated in proportion to their volume, with the reference's argon_radius insets
-    (Pore:115-139): r = (R - r_ar) * sqrt(u), theta ~ U(0, 2pi), z ~ U(z_lo, z_hi)."""
-    rng = np.random.default_rng(seed)
-    n = int(p.n)
+def pore_regions(p, consts):
+    """(counts, [(radius, z_lo, z_hi)]) of the five stacked cylinders, populated in proportion to their volume, with the
+    reference's argon_radius insets (Pore:115-139)."""
     c = consts
+    n = int(p.n)
     ar = p.argon_radius
     oa, hot, gap, cold = (c["open_air_particles"], c["hot_pore_particles"], c["gap_particles"],
                           c["cold_pore_particles"])
@@ -42,6 +41,14 @@ def pore_ic(p, consts, seed=17):
         (c["pore_coated_radius"] - ar, h_oa + h_hot + h_gap, h_oa + h_hot + h_gap + h_cold),
         (c["open_air_radius"] - ar, h_oa + h_hot + h_gap + h_cold + ar, H - ar),
     ]
+    return counts, regions
+
+
+def pore_ic(p, consts, seed=17):
+    """r = (R - r_ar) * sqrt(u), theta ~ U(0, 2pi), z ~ U(z_lo, z_hi) per region (Pore:120-139)."""
+    rng = np.random.default_rng(seed)
+    n = int(p.n)
+    counts, regions = pore_regions(p, consts)
     x = np.empty(n); y = np.empty(n); z = np.empty(n)
     o = 0
     for cnt, (R, zlo, zhi) in zip(counts, regions):
@@ -53,3 +60,24 @@ def pore_ic(p, consts, seed=17):
         o += cnt
     vx, vy, vz = maxwell_velocities(n, consts["a_shape"], rng)
     return x, y, z, vx, vy, vz
+
+
+def device_ic_config(p, consts, seed, kind):
+    """amc_ic_config for ``Engine.init_synthetic``: the same regions and Maxwell scale as cube_ic / pore_ic, generated on
+    the GPU from a counter-based generator (include/argonmc.h) — a different random stream than the host generators."""
+    import ctypes as C
+    from ._abi import AmcIcConfig
+    g = AmcIcConfig()
+    g.struct_size, g.seed, g.a_shape = C.sizeof(AmcIcConfig), int(seed) & 0xFFFFFFFFFFFFFFFF, float(consts["a_shape"])
+    if kind == "cube":
+        g.n_regions = 0
+        return g
+    counts, regions = pore_regions(p, consts)
+    g.n_regions = len(regions)
+    o = 0
+    for r, (cnt, (R, zlo, zhi)) in enumerate(zip(counts, regions)):
+        g.first[r] = o
+        g.radius[r], g.z_lo[r], g.z_hi[r] = float(R), float(zlo), float(zhi)
+        o += int(cnt)
+    g.first[len(regions)] = o
+    return g

@@ -56,10 +56,16 @@ class Simulation:
                            dist_x_since_collision, dist_y_since_collision, dist_z_since_collision, full_path_traveled)
         self._cache = None
 
-    def init_synthetic(self, seed=None):
-        """Seeded synthetic initial conditions — the reference's own generators are host-side, one-off."""
+    def init_synthetic(self, seed=None, device=False):
+        """Seeded synthetic initial conditions — the reference's own generators are host-side, one-off.
+        ``device=True`` generates them on the GPU (counter-based generator: another random stream, no PCIe transfer)."""
+        seed = seed if seed is not None else self.consts["seed"]
+        if device:
+            self.engine.init_synthetic(IC.device_ic_config(self.params, self.consts, seed, "cube" if self.kind == "cube" else "pore"))
+            self._cache = None
+            return
         gen = IC.cube_ic if self.kind == "cube" else IC.pore_ic
-        self.set_state(*gen(self.params, self.consts, seed if seed is not None else self.consts["seed"]))
+        self.set_state(*gen(self.params, self.consts, seed))
 
     def _state(self):
         if self._cache is None:
@@ -202,8 +208,13 @@ class TemperatureSimulation(Simulation):
         self.energy_transfer_cold_per_step = []       # Temp:638
         self._zero_flags = []
 
-    def init_synthetic(self, seed=None):
-        self.set_state(*IC.pore_ic(self.params, self.consts, seed if seed is not None else self.consts["seed"]))
+    def init_synthetic(self, seed=None, device=False):
+        seed = seed if seed is not None else self.consts["seed"]
+        if device:
+            self.engine.init_synthetic(IC.device_ic_config(self.params, self.consts, seed, "pore"))
+            self._cache = None
+            return
+        self.set_state(*IC.pore_ic(self.params, self.consts, seed))
 
     def timestep(self, dt=None, collect_paths=True):
         if self._device_rng is not None:

@@ -248,6 +248,23 @@ int amc_temp_device_sums(amc_ctx *ctx, double *sums /*[3]*/, int32_t *had /*[3]*
 int amc_temp_device_draws(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, double *contact_z, double *dir_xyz,
                           double *surface_energy, size_t cap, size_t *n);
 
+/* ---- synthetic initial conditions on the device (opt-in) ------------------------------------------
+ * The recipe of the reference's generators (Cube:144-172, Pore:106-158): positions uniform per region — the cube, or
+ * stacked cylinders with r = radius * sqrt(u), theta ~ U(0, 2 pi), z ~ U(z_lo, z_hi) (Pore:120-139; the caller applies
+ * the argon_radius insets) — velocity components N(0, a_shape^2) (Maxwell speeds, isotropic directions; Pore:144-158),
+ * path accumulators zero, flag clear.  The numbers come from Philox4x32-10 with counter (particle, block, 0, tag): they
+ * depend on the seed and the particle index only, so every rank of a sharded run builds the identical system.  NOT the
+ * reference's scipy / NumPy streams.  Replaces amc_upload for such runs; asynchronous on the context's stream. */
+typedef struct amc_ic_config {
+    int32_t struct_size;          /* sizeof(amc_ic_config)                                                       */
+    int32_t n_regions;            /* 0: uniform in [0,cube_x) x [0,cube_y) x [0,cube_z); 1..8: stacked cylinders */
+    uint64_t seed;
+    double a_shape;               /* Maxwell scale sqrt(kT/m) (Pore:56, Cube:56)                                 */
+    int64_t first[9];             /* region r holds the particles [first[r], first[r+1])                         */
+    double radius[8], z_lo[8], z_hi[8];
+} amc_ic_config;
+int amc_init_synthetic(amc_ctx *ctx, const amc_ic_config *cfg);
+
 /* ---- multi-GPU (one process per GPU; particles sharded by index range) ------------------------------
  * Every rank allocates all n particles but advances only its shard [lo, hi); the reference has no counterpart (its
  * parallelism is multiprocessing.Pool over cells, Pore:404-406, 546).  Per step (argon_monte_carlo_amd/dist.py):

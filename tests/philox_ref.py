@@ -22,3 +22,14 @@ def direction_draw(seed, particle, step, case, attempt):
     u1 = (((c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0)
     u2 = (((c[2] << 32) | c[3]) >> 12) * (1.0 / 4503599627370496.0)
     return -1.0 + 2.0 * u1, math.pi * u2, (1.0 if (c[3] & 1) else -1.0)
+
+
+def ic_uniforms(seed, particle):
+    """The eight uniform doubles k_ic (amc_ic.hip) forms for one particle: Philox blocks 0..3 with counter
+    (particle, block, 0, "AMCI"), two 53-bit numbers per block."""
+    out = []
+    for blk in range(4):
+        c = philox4x32_10([particle, blk, 0, 0x414d4349], [seed & MASK, (seed >> 32) & MASK])
+        out.append((((c[0] << 32) | c[1]) >> 11) * (1.0 / 9007199254740992.0))
+        out.append((((c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0))
+    return out

@@ -25,7 +25,7 @@ def _case(kind, n):
     return p, c, init
 
 
-def _worker(rank, world, port, kind, n, steps, q):
+def _worker(rank, world, port, kind, n, steps, q, device_ic_seed=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +33,11 @@ def _worker(rank, world, port, kind, n, steps, q):
         from argon_monte_carlo_amd.dist import ShardedSimulation
         p, c, init = _case(kind, n)
         sim = ShardedSimulation(p, rank, world, backend="gloo")
-        sim.upload(*init)
+        if device_ic_seed is None:
+            sim.upload(*init)
+        else:
+            from argon_monte_carlo_amd import ic as IC
+            sim.init_synthetic(IC.device_ic_config(p, c, device_ic_seed, kind))
         tot = sim.run(c["dt"], steps)
         full = sim.download()
         counts, npaths = sim.histograms()
@@ -79,6 +83,32 @@ def test_ranks_on_one_gpu_equal_single_engine(kind, n, steps, world):
     for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
         assert tot[k] == ref_tot[k], (k, tot, ref_tot)
     assert npaths == ref_npaths and np.array_equal(counts, ref_counts)
+
+
+def test_device_initial_conditions_do_not_depend_on_the_shard_layout():
+    """amc_init_synthetic on every rank of a 2-rank run == on a single context (then 6 steps, bit for bit)."""
+    from argon_monte_carlo_amd import ic as IC
+    from argon_monte_carlo_amd.engine import Engine
+    kind, n, steps, seed = "pore", 120001, 6, 5
+    p, c, _ = _case(kind, n)
+    eng = Engine(p)
+    eng.init_synthetic(IC.device_ic_config(p, c, seed, kind))
+    ref_tot = eng.run(c["dt"], steps)
+    ref = eng.download()
+    eng.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, n, steps, q, seed)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    full, tot, counts, npaths = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for k in KEYS:
+        assert np.array_equal(full[k], ref[k]), (k, np.flatnonzero(full[k] != ref[k])[:5])
+    assert tot["n_pp"] == ref_tot["n_pp"] > 0 and tot["n_wall"] == ref_tot["n_wall"]
 
 
 # ---- energised walls (Temperature_Pore_MC.py) over two shards ---------------------------------------------------------------------

@@ -831,3 +831,63 @@ def test_candidate_overflow_in_the_large_sweep_plan_is_reported(Engine):
     st = eng.download()
     assert np.all(np.isfinite(st["x"]))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- device-side initial conditions
+def test_device_initial_conditions_cube(Engine):
+    """amc_init_synthetic, cube: the documented mapping of Philox numbers to positions / velocities
+    (positions bit for bit, velocities to the libm/ocml difference), bounds, moments, determinism."""
+    import math
+    from tests.philox_ref import ic_uniforms
+    n, seed = 200_000, 12345
+    p, c = PR.cube_params_for_n(n)
+    eng = Engine(p)
+    eng.init_synthetic(IC.device_ic_config(p, c, seed, "cube"))
+    s = eng.download()
+    a = c["a_shape"]
+    for q in (0, 1, 77_777, n - 1):
+        u = ic_uniforms(seed, q)
+        assert s["x"][q] == u[0] * p.cube_x and s["y"][q] == u[1] * p.cube_y and s["z"][q] == u[2] * p.cube_z
+        m0, m1 = math.sqrt(-2.0 * math.log(1.0 - u[3])), math.sqrt(-2.0 * math.log(1.0 - u[5]))
+        want = (a * m0 * math.cos(2 * math.pi * u[4]), a * m0 * math.sin(2 * math.pi * u[4]), a * m1 * math.cos(2 * math.pi * u[6]))
+        np.testing.assert_allclose([s["vx"][q], s["vy"][q], s["vz"][q]], want, rtol=1e-12)
+    for k, L in (("x", p.cube_x), ("y", p.cube_y), ("z", p.cube_z)):
+        assert s[k].min() >= 0.0 and s[k].max() < L
+        assert abs(s[k].mean() / L - 0.5) < 5 * (1 / 12) ** 0.5 / n ** 0.5
+    for k in ("vx", "vy", "vz"):
+        assert abs(s[k].mean()) < 5 * a / n ** 0.5                       # N(0, a^2) components
+        assert abs(s[k].var() / a ** 2 - 1.0) < 5 * (2.0 / n) ** 0.5
+    for k in ("d", "dx", "dy", "dz", "flag"):
+        assert not s[k].any()
+    eng2 = Engine(p)
+    eng2.init_synthetic(IC.device_ic_config(p, c, seed, "cube"))
+    assert_state_equal(eng2.download(), s, "device ic: same seed")
+    eng2.init_synthetic(IC.device_ic_config(p, c, seed + 1, "cube"))
+    assert not np.array_equal(eng2.download()["x"], s["x"])
+    st = eng.run(c["dt"], 5)                                             # and the state is usable: a few steps run
+    assert st["n_pp"] > 0 and st["flags"] == 0
+    eng.close(); eng2.close()
+
+
+def test_device_initial_conditions_pore(Engine):
+    """amc_init_synthetic, pore: every particle inside its region with the reference's insets (Pore:120-139), region
+    populations as ic.pore_regions says, radial density uniform (mean r^2 = R^2 / 2), and the bounds check finds nobody outside."""
+    n, seed = 300_000, 17
+    p, c = PR.pore_params(n=n)
+    eng = Engine(p)
+    eng.init_synthetic(IC.device_ic_config(p, c, seed, "pore"))
+    s = eng.download()
+    counts, regions = IC.pore_regions(p, c)
+    o = 0
+    for cnt, (R, zlo, zhi) in zip(counts, regions):
+        sl = slice(o, o + cnt)
+        r2 = s["x"][sl] ** 2 + s["y"][sl] ** 2
+        assert r2.max() <= R * R * (1 + 1e-12) and s["z"][sl].min() >= zlo and s["z"][sl].max() <= zhi
+        assert abs(r2.mean() / (R * R) - 0.5) < 5 * (1 / 12) ** 0.5 / cnt ** 0.5
+        assert abs((s["z"][sl].mean() - zlo) / (zhi - zlo) - 0.5) < 5 * (1 / 12) ** 0.5 / cnt ** 0.5
+        o += cnt
+    assert o == n
+    assert eng.stage_bounds() == 0                                         # nobody starts outside (Pore:354-375 finds nothing)
+    st = eng.run(c["dt"], 3)
+    assert st["flags"] == 0 and st["n_pp"] > 0 and st["n_wall"] > 0
+    eng.close()
