@@ -177,6 +177,7 @@ void amc_destroy(amc_ctx *c)
       for (void *q : td) if (q) hipFree(q); }
     if (c->kin_send) hipFree(c->kin_send);
     if (c->kin_recv) hipFree(c->kin_recv);
+    if (c->kin_vpub) hipFree(c->kin_vpub);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -223,7 +224,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
     c->plan_small = AMC_PLAN_SMALL;
     if (const char *e = getenv("AMC_PLAN_SMALL")) { const int v = atoi(e); if (v >= 0) c->plan_small = v; }
-    c->kin_send = c->kin_recv = nullptr; c->kin_world = 0; c->kin_m = 0; c->kin_lists = false;
+    c->kin_send = c->kin_recv = c->kin_vpub = nullptr; c->kin_world = 0; c->kin_m = c->kin_cap = c->kin_block = 0; c->kin_lists = false;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
     c->stream = nullptr;
@@ -390,8 +391,19 @@ int amc_upload(amc_ctx *c, const double *x, const double *y, const double *z, co
     for (int k = 0; k < 10; k++)
         if (src[k] && nb) AMC_HIP(c, hipMemcpyAsync(dst[k], src[k], nb, hipMemcpyHostToDevice, c->stream));
     if (full_path && c->n) AMC_HIP(c, hipMemcpyAsync(c->S.flag, full_path, (size_t)c->n, hipMemcpyHostToDevice, c->stream));
+    { int rc_ = amc_publish_velocities(c); if (rc_) return rc_; }
     AMC_HIP(c, hipStreamSynchronize(c->stream));
     c->uploaded = true;
+    return AMC_OK;
+}
+
+int amc_publish_velocities(amc_ctx *c)
+{
+    if (!c->kin_vpub || c->n <= 0) return AMC_OK;       // not a sharded context
+    const size_t nb = sizeof(double) * (size_t)c->n;
+    const double *src[3] = {c->S.vx, c->S.vy, c->S.vz};
+    for (int e = 0; e < 3; e++)
+        AMC_HIP(c, hipMemcpyAsync(c->kin_vpub + (size_t)e * (size_t)c->n, src[e], nb, hipMemcpyDeviceToDevice, c->stream));
     return AMC_OK;
 }
 
@@ -467,14 +479,14 @@ int amc_finish_stats(amc_ctx *c, amc_step_stats *out)
     delta_stats(now, c->h_prev, &st);
     c->h_prev = now;
     if (out) *out = st;
-    if (now.flags & 5ULL) {     // candidate / resolve work-space overflow; a full path-record buffer (bit1) only stops recording
+    if (now.flags & 21ULL) {    // candidate / resolve work-space / velocity-change list overflow; a full path-record buffer (bit1) only stops recording
         const unsigned long long f = now.flags;
         // clear the sticky flags on the device so that a later call can succeed after the caller drained / resized
         unsigned long long zero = 0;
         hipMemcpyAsync(&c->d_cnt->flags, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream);
         hipStreamSynchronize(c->stream);
         c->h_prev.flags = 0;
-        return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 4 resolve work space)", f);
+        return amc_fail(c, AMC_ERR_CAPACITY, "device work buffer overflow (flags=%llu: 1 candidates, 4 resolve work space, 16 velocity changes of one step in the multi-GPU exchange)", f);
     }
     if (st.n_fp_errors > 0 && c->P.geometry != AMC_GEOM_PORE_ENERGISED && !(c->P.reserved1 & 1))
         return amc_fail(c, AMC_ERR_FP, "%lld event(s) where the reference raises FloatingPointError", (long long)st.n_fp_errors);

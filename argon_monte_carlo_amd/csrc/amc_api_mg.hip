@@ -1,5 +1,5 @@
 // amc_api_mg.hip — C ABI of the multi-GPU path (one process per GPU, index-range shards): shard-local step,
-// packed exchange of positions and velocities, then the single-GPU sweep over the whole system on every rank.
+// packed exchange of positions and changed velocities, then the single-GPU sweep over the whole system on every rank.
 #include "amc_host.h"
 
 extern "C" {
@@ -9,6 +9,9 @@ int amc_set_shard(amc_ctx *c, int64_t lo, int64_t hi)
     if (!c || lo < 0 || hi < lo || hi > c->n) return AMC_ERR_INVALID;
     c->lo = lo; c->hi = hi;
     c->mg_count_pp = (lo == 0);     // the rank that owns particle 0 reports the sweep's collision count
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (!c->kin_vpub) AMC_HIP(c, hipMalloc((void **)&c->kin_vpub, sizeof(double) * 3 * (size_t)std::max<int64_t>(c->n, 1)));
+    if (c->uploaded) return amc_publish_velocities(c);
     return AMC_OK;
 }
 
@@ -23,9 +26,9 @@ int amc_mg_local(amc_ctx *c, double dt)
     return AMC_OK;
 }
 
-int amc_mg_exchange_view(amc_ctx *c, int world, void **send, void **recv, int64_t *m)
+int amc_mg_exchange_view(amc_ctx *c, int world, void **send, void **recv, int64_t *block)
 {
-    if (!c || world < 1 || !send || !recv || !m) return AMC_ERR_INVALID;
+    if (!c || world < 1 || !send || !recv || !block) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->kin_world != world) {
         AMC_HIP(c, hipStreamSynchronize(c->stream));
@@ -33,13 +36,17 @@ int amc_mg_exchange_view(amc_ctx *c, int world, void **send, void **recv, int64_
         if (c->kin_recv) hipFree(c->kin_recv);
         c->kin_send = c->kin_recv = nullptr;
         c->kin_world = 0;
-        c->kin_m = (c->n + world - 1) / world;
-        const size_t mm = (size_t)std::max<int64_t>(c->kin_m, 1);
-        AMC_HIP(c, hipMalloc((void **)&c->kin_send, sizeof(double) * 6 * mm));
-        AMC_HIP(c, hipMalloc((void **)&c->kin_recv, sizeof(double) * 6 * mm * (size_t)world));
+        c->kin_m = std::max<int64_t>((c->n + world - 1) / world, 1);
+        c->kin_cap = std::max<int64_t>(4096, c->kin_m / 8);
+        if (const char *e = getenv("AMC_MG_VELOCITY_LIST")) { const long long v = atoll(e); if (v > 0) c->kin_cap = v; }   // (tests)
+        const int64_t kb = amc_kin_banks();
+        c->kin_cap = (c->kin_cap + kb - 1) / kb * kb;                   // the same room in every bank
+        c->kin_block = 3 * c->kin_m + kb + 4 * c->kin_cap;
+        AMC_HIP(c, hipMalloc((void **)&c->kin_send, sizeof(double) * (size_t)c->kin_block));
+        AMC_HIP(c, hipMalloc((void **)&c->kin_recv, sizeof(double) * (size_t)c->kin_block * (size_t)world));
         c->kin_world = world;
     }
-    *send = c->kin_send; *recv = c->kin_recv; *m = c->kin_m;
+    *send = c->kin_send; *recv = c->kin_recv; *block = c->kin_block;
     return AMC_OK;
 }
 

@@ -52,5 +52,6 @@ struct amc_stage {
 #define AMC_INTERNAL extern "C" __attribute__((visibility("hidden")))
 AMC_INTERNAL int amc_read_counters(amc_ctx *c, amc_dev_counters *h);    // device counters with the banks folded in (synchronises)
 AMC_INTERNAL int amc_finish_stats(amc_ctx *c, amc_step_stats *out);     // per-step deltas + error flags
+AMC_INTERNAL int amc_publish_velocities(amc_ctx *c);                    // multi-GPU: vpub = current velocities (after an upload)
 AMC_INTERNAL int amc_flush(amc_ctx *c);                                 // write deferred sweep results to the particle arrays
 AMC_INTERNAL int amc_enqueue_sweep(amc_ctx *c, bool counted = false, bool defer_commit = false);   // bin (unless counted) + detect + resolve

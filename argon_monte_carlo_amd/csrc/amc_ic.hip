@@ -67,5 +67,5 @@ extern "C" int amc_init_synthetic(amc_ctx *c, const amc_ic_config *cfg)
         AMC_HIP(c, hipGetLastError());
     }
     c->uploaded = true;
-    return AMC_OK;
+    return amc_publish_velocities(c);
 }

@@ -149,9 +149,11 @@ struct amc_ctx {
     // pinned host staging for the small per-step read-backs (a copy into pageable memory costs ~100 us on this stack)
     char *h_pin;
     size_t h_pin_bytes;
-    double *kin_send, *kin_recv;   // packed exchange of positions and velocities: [6][m] and [world][6][m]
+    double *kin_send, *kin_recv;   // per-step exchange (amc_exchange.hip): one block of kin_block doubles, and world of them
+    double *kin_vpub;              // [3][n] velocities as last published to the other ranks (allocated by amc_set_shard;
+                                   // every upload publishes: all ranks upload the same full state)
     int kin_world;
-    int64_t kin_m;
+    int64_t kin_m, kin_cap, kin_block;   // shard length (padded), capacity of the velocity-change list (all banks), 3m + banks + 4cap
     bool kin_lists;                // amc_mg_pack started this step's per-cell lists (the unpack completes them)
 };
 
@@ -187,6 +189,7 @@ hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
 hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg);
 hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack);
+int amc_kin_banks(void);         // banks of the velocity-change list in an exchange block
 // the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
 struct amc_resolve_ctl {
     int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;

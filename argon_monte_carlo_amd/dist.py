@@ -1,7 +1,7 @@
 """Multi-GPU driver: one process per GPU, particles sharded by contiguous index range.
 
 Per step every rank advances only its shard (drift + walls + bounds), then ONE all-gather over RCCL/xGMI hands the
-positions and velocities of every shard to everybody (48 B per particle), and every rank runs the p-p sweep of the whole
+positions of every shard and the velocities that changed to everybody (~28 B per particle), and every rank runs the p-p sweep of the whole
 system exactly as a single GPU would (bin, detect, ordered resolve, commit).  All ranks compute every collision from
 identical inputs, so cross-shard pairs and chains need no locking, no ownership logic inside the kernels and no further
 exchange: the path accumulators and the flag of a particle only feed its own bookkeeping and are meaningful on its owner
@@ -121,7 +121,7 @@ class ShardedSimulation:
         return self._sweep(reduce_stats, want_stats)
 
     def _sweep(self, reduce_stats=True, want_stats=True):
-        """positions + velocities of all shards -> everybody, then the sweep of the whole system on every rank"""
+        """positions (+ changed velocities) of all shards -> everybody, then the sweep of the whole system on every rank"""
         e = self.engine
         if not (self.world == 1 and self.comm.shortcut):
             send, recv = e.exchange_buffers(self.world)

@@ -187,12 +187,12 @@ class ShardEngine(Engine):
         return torch.as_tensor(d, device="cuda")
 
     def exchange_buffers(self, world):
-        """(send, recv) tensors of the all-gather: float64[6*m] (x|y|z|vx|vy|vz of the shard) and float64[world*6*m]."""
+        """(send, recv) tensors of the all-gather: this rank's block (float64[block]: positions of the shard + the list of
+        velocity changes) and the blocks of all ranks (float64[world * block])."""
         if getattr(self, "_xb_world", None) != world:
-            send, recv, m = C.c_void_p(), C.c_void_p(), C.c_int64(0)
-            self._ck(self.lib.amc_mg_exchange_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(m)))
-            mm = max(1, m.value)
-            self._xb = (self._wrap(send.value, 6 * mm, "<f8"), self._wrap(recv.value, 6 * mm * world, "<f8"))
+            send, recv, blk = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+            self._ck(self.lib.amc_mg_exchange_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(blk)))
+            self._xb = (self._wrap(send.value, blk.value, "<f8"), self._wrap(recv.value, blk.value * world, "<f8"))
             self._xb_world = world
         return self._xb
 

@@ -194,7 +194,7 @@ def main():
                 tot = st if tot is None else {kk: tot[kk] + st[kk] for kk in st}
             return tot
         parallelism = ("single GPU" if not sharded else f"index-range shards x{world}, hits concatenated in index order, "
-                       "one all-gather of positions + velocities per step (RCCL)") + \
+                       "one all-gather per step: positions + changed velocities (RCCL)") + \
             (" + device-side Philox sampling (opt-in, NOT the reference's random streams)" if args.device_rng else
              " + host RNG/mpmath hand-over per energised case")
         engines = [eng.engine if sharded else eng]
@@ -228,7 +228,7 @@ def main():
         sim = ShardedSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
         sim.upload(*init)
         step = lambda k: sim.run(c["dt"], k)          # noqa: E731
-        parallelism = f"index-range shards x{world}, one all-gather of positions + velocities per step (RCCL)"
+        parallelism = f"index-range shards x{world}, one all-gather per step: positions + changed velocities (RCCL)"
         engines = [sim.engine]
 
     def sync():

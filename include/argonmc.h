@@ -124,7 +124,7 @@ typedef struct amc_step_stats {
     int64_t n_clusters;           /* interaction clusters resolved                                     */
     int64_t n_rounds;             /* resolve validation rounds (1 = no cluster merge was needed)       */
     int64_t n_fp_errors;          /* events where the reference would raise (a == 0, negative discriminant) */
-    int64_t flags;                /* bit0 candidate overflow, bit1 path overflow, bit2 cluster overflow */
+    int64_t flags;                /* bit0 candidate overflow, bit1 path overflow, bit2 cluster overflow, bit4 velocity-change list (multi-GPU) */
 } amc_step_stats;
 
 /* One completed free path (Pore:186-199, 274-278, 324-328).  (step, phase, cell, i, j, which) is the position of
@@ -269,16 +269,19 @@ int amc_init_synthetic(amc_ctx *ctx, const amc_ic_config *cfg);
  * Every rank allocates all n particles but advances only its shard [lo, hi); the reference has no counterpart (its
  * parallelism is multiprocessing.Pool over cells, Pore:404-406, 546).  Per step (argon_monte_carlo_amd/dist.py):
  *   amc_mg_local            drift + walls + bounds on [lo,hi)                       (Pore:426-512 on the shard)
- *   amc_mg_pack             x|y|z|vx|vy|vz of the shard -> send buffer (and the shard's particles into the per-cell
- *                           lists of the detection grid: the pack and unpack kernels see every final position once)
- *   <all-gather>            RCCL over xGMI: send of every rank -> recv (48 B per particle and step)
- *   amc_mg_sweep            recv -> position and velocity arrays (and per-cell lists) of the other shards, then the
- *                           p-p sweep of the WHOLE system exactly as on one GPU (detect, ordered resolve, commit): every rank
- *                           computes every collision from identical positions and velocities, so cross-shard pairs
- *                           and chains need no further exchange.  The path accumulators and the flag of a particle
- *                           matter only to its own bookkeeping: they are meaningful on the owner alone, which is
- *                           also the one that emits the particle's completed paths; the collision count is reported
- *                           by the rank that owns particle 0.
+ *   amc_mg_pack             this rank's block -> send buffer: the positions of the shard and the list of its particles
+ *                           whose velocity differs bitwise from what was last published (a collision or a wall: a
+ *                           fraction of a per cent per step); the shard's particles go into the per-cell lists of the
+ *                           detection grid on the way (the pack and unpack kernels see every final position once)
+ *   <all-gather>            RCCL over xGMI: send of every rank -> recv (about 28 B per particle and step)
+ *   amc_mg_sweep            recv -> positions (and per-cell lists) of the other shards, their velocity changes applied,
+ *                           then the p-p sweep of the WHOLE system exactly as on one GPU (detect, ordered resolve):
+ *                           every rank computes every collision from identical positions and velocities, so cross-shard
+ *                           pairs and chains need no further exchange.  The path accumulators and the flag of a
+ *                           particle matter only to its own bookkeeping: they are meaningful on the owner alone, which
+ *                           is also the one that emits the particle's completed paths; the collision count is
+ *                           reported by the rank that owns particle 0.  Results reach the arrays of the owner through
+ *                           its next streaming pass; the other ranks learn them from the owner's next block.
  *   amc_mg_finish           bounds check after the sweep on [lo,hi), step counter, per-step counters
  * Nothing in the step waits for the host.  Energised walls (Temp:662-853) shard the same way: amc_temp_begin /
  * amc_wall_hits / amc_wall_apply act on [lo,hi); the host concatenates the hits of all ranks in rank order (=
@@ -287,12 +290,16 @@ int amc_init_synthetic(amc_ctx *ctx, const amc_ic_config *cfg);
  * without a counter read-back; the sweep then runs as above. */
 int amc_set_shard(amc_ctx *ctx, int64_t lo, int64_t hi);
 int amc_mg_local(amc_ctx *ctx, double dt);
-/* Buffers of the all-gather.  With m = ceil(n / world): send = float64[6][m], this rank's x|y|z|vx|vy|vz shard (zero
- * padded); recv = float64[world][6][m], the send blocks of all ranks in rank order (the output of an all-gather of
- * `send`).  Shards follow the driver's rule: rank r owns base + (r < n % world) particles starting at
- * r * base + min(r, n % world), base = n / world.  The pointers stay valid until the context is destroyed or the
- * function is called with another world size. */
-int amc_mg_exchange_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *m);
+/* Buffers of the all-gather.  One block per rank: with m = ceil(n / world) and cap = max(4096, m / 8),
+ *   float64[3][m] x|y|z of the shard (zero padded) | int64 count[16] | 16 lists of (particle, vx, vy, vz), room for
+ *   cap / 16 each (the velocity changes are collected in 16 banks, one per workgroup modulo 16)
+ * *block = 3 m + 16 + 4 cap float64; send holds this rank's block, recv the blocks of all ranks in rank order (the
+ * output of an all-gather of `send`).  A bank that overflows in one step sets flag bit 4 (AMC_ERR_CAPACITY at the next
+ * amc_mg_finish with statistics).  Shards follow the driver's rule: rank r owns base + (r < n % world)
+ * particles starting at r * base + min(r, n % world), base = n / world.  Every rank uploads the same full state, which counts
+ * as published (amc_upload / amc_init_synthetic on a sharded context, or amc_set_shard on an uploaded one).  The pointers stay valid until the context is
+ * destroyed or the function is called with another world size. */
+int amc_mg_exchange_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *block);
 int amc_mg_pack(amc_ctx *ctx, int world);
 int amc_mg_sweep(amc_ctx *ctx, int world, int rank);       /* world == 1: no unpack (nothing was exchanged) */
 int amc_mg_bounds(amc_ctx *ctx);

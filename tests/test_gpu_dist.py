@@ -111,6 +111,25 @@ def test_device_initial_conditions_do_not_depend_on_the_shard_layout():
     assert tot["n_pp"] == ref_tot["n_pp"] > 0 and tot["n_wall"] == ref_tot["n_wall"]
 
 
+def test_velocity_change_list_overflow_is_reported(monkeypatch):
+    """More velocity changes in one step than the exchange block has room for (forced: room for two) must surface as
+    AMC_ERR_CAPACITY, not as silently stale velocities on the other ranks."""
+    from argon_monte_carlo_amd._lib import ArgonMCError
+    from argon_monte_carlo_amd.engine import ShardEngine
+    monkeypatch.setenv("AMC_MG_VELOCITY_LIST", "2")
+    p, c, init = _case("cube", 50000)
+    e = ShardEngine(p, 0, 50000)
+    e.upload(*init)
+    e.exchange_buffers(1)
+    with pytest.raises(ArgonMCError, match="velocity changes"):
+        for _ in range(3):                      # wall hits of step 1 and collisions of the sweeps change > 2 velocities
+            e.mg_local(c["dt"])
+            e.mg_pack(1)
+            e.mg_sweep(1, 0)
+            e.mg_finish(True)
+    e.close()
+
+
 # ---- energised walls (Temperature_Pore_MC.py) over two shards ---------------------------------------------------------------------
 def _temp_case(n):
     from argon_monte_carlo_amd import ic as IC, params as PR
