@@ -1,8 +1,8 @@
-"""Long parity run on the GPU box: the HIP path and the CPU oracle advance the same workload side by side; the state
+"""Test infrastructure (run by hand / through gpurun, not collected by pytest).  Long parity run on the GPU box: the HIP path and the CPU oracle advance the same workload side by side; the state
 is compared bit for bit every `chunk` steps and the device histograms with np.histogram of the oracle's completed
 paths at the end.  Writes a JSON summary (committed under profiles/ as evidence).
 
-    python tools/soak.py pore_1e6 1000 100
+    python tests/soak.py pore_1e6 1000 100
 """
 import json
 import os

@@ -1,8 +1,8 @@
-"""Long parity run of the multi-GPU driver on ONE GPU: `world` ranks (gloo, collectives staged through the host — RCCL
+"""Test infrastructure (run by hand / through gpurun, not collected by pytest).  Long parity run of the multi-GPU driver on ONE GPU: `world` ranks (gloo, collectives staged through the host — RCCL
 refuses several ranks on one device) against the single-context engine on the same workload; state, counters and
 histograms must be identical.  Writes a JSON summary (committed under profiles/ as evidence).
 
-    python tools/soak_sharded.py pore_1e6 200 2
+    python tests/soak_sharded.py pore_1e6 200 2
 """
 import json
 import os
