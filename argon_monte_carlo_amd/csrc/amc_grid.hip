@@ -21,8 +21,8 @@
 #define AMC_CR2_INFLATE (1.0 + 1.0e-9)
 
 // ---- binning: per-cell particle lists ------------------------------------------------------------------------------------
-// stand-alone form (the step driver builds the lists inside k_stream; this one serves the stage API and multi-GPU,
-// where positions arrive through the all-gather)
+// stand-alone form (the step driver builds the lists inside k_stream, the multi-GPU path inside its pack / unpack
+// kernels; this one serves the stage API)
 __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ z, long long n, amc_grid G, amc_lists B,
                                                    amc_dev_counters *cnt)

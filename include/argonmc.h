@@ -308,7 +308,7 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 /* ---- measurement ----------------------------------------------------------------------------------------- */
 /* With profiling on, every kernel launch is bracketed by hipEvents on the launch stream. */
 #define AMC_K_DRIFT_WALLS 0
-#define AMC_K_BIN_COUNT 1        /* k_bin_lists: stand-alone build of the per-cell lists (the step driver fuses it into k_stream) */
+#define AMC_K_BIN_COUNT 1        /* k_bin_lists (stand-alone list build; the step driver fuses it into k_stream) and the multi-GPU pack / unpack kernels, which build the lists too */
 #define AMC_K_BIN_SCAN 2         /* reserved (no such pass: the lists need neither scan nor scatter) */
 #define AMC_K_BIN_SCATTER 3      /* reserved */
 #define AMC_K_DETECT 4
