@@ -105,6 +105,7 @@ class ShardedSimulation:
             engine.set_stream(stream_ptr)
         self.engine = engine
         self.comm = comm if comm is not None else TorchComm(rank, world)
+        self._comm_events = None
 
     def upload(self, *arrays, **kw):
         """Every rank uploads the full initial state (only its shard of the non-position arrays is ever used)."""
@@ -126,7 +127,15 @@ class ShardedSimulation:
         if not (self.world == 1 and self.comm.shortcut):
             send, recv = e.exchange_buffers(self.world)
             e.mg_pack(self.world)
-            self.comm.allgather_packed(send, recv)
+            if self._comm_events is None:
+                self.comm.allgather_packed(send, recv)
+            else:                                   # measurement: the collective bracketed by events on the launch stream
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.comm.allgather_packed(send, recv)
+                b.record()
+                self._comm_events.append((a, b))
         e.mg_sweep(self.world, self.rank)
         st = e.mg_finish(want_stats)
         if st is None:
@@ -135,6 +144,21 @@ class ShardedSimulation:
             tot = self.comm.allreduce_sum_ints([st[k] for k in self.SUM_KEYS])
             st.update(dict(zip(self.SUM_KEYS, tot)))
         return st
+
+    def profile_collective(self, enable):
+        """Bracket every all-gather with events on the launch stream (bench.py's per-kernel pass, GPU engines only)."""
+        self._comm_events = [] if enable else None
+
+    def collective_times(self):
+        """(total milliseconds, count) of the bracketed all-gathers since profile_collective(True); synchronises."""
+        ev = self._comm_events or []
+        if not ev:
+            return 0.0, 0
+        ev[-1][1].synchronize()
+        tot = sum(a.elapsed_time(b) for a, b in ev)
+        n = len(ev)
+        self._comm_events = []
+        return tot, n
 
     def run(self, dt, nsteps):
         acc = None

@@ -31,7 +31,7 @@ ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 
 KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_lists",
                    "detect": "k_detect_lists", "resolve": "k_resolve<GEOM,0> (first launch of the sweep)",
                    "bounds": "k_stream (bounds-only pass)", "validate": "k_validate", "resolve_more": "k_resolve<GEOM,1>",
-                   "commit": "k_commit"}
+                   "commit": "k_commit", "allgather": "all-gather (RCCL)"}
 
 WORKLOADS = {
     "cube_1e5": ("cube", 100_000),
@@ -159,6 +159,7 @@ def main():
     if args.n:
         n_per_gpu = args.n
     stream_ptr = torch.cuda.current_stream().cuda_stream
+    driver = None                                       # the multi-GPU driver object, when one is in use
 
     if kind == "temp":
         import random
@@ -172,6 +173,7 @@ def main():
         if sharded:
             from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
             eng = ShardedTemperatureSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
+            driver = eng
         else:
             eng = EnergisedEngine(p)
             eng.set_stream(stream_ptr)
@@ -226,6 +228,7 @@ def main():
         n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
         sim = ShardedSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
+        driver = sim
         sim.upload(*init)
         step = lambda k: sim.run(c["dt"], k)          # noqa: E731
         parallelism = f"index-range shards x{world}, one all-gather per step: positions + changed velocities (RCCL)"
@@ -251,15 +254,20 @@ def main():
     # per-kernel durations: the same K steps again with every launch bracketed by hipEvents on the launch stream
     eng0 = engines[0]
     eng0.profile(True)
+    if driver is not None:
+        driver.profile_collective(True)
     step(args.steps)
     sync()
     kt = eng0.kernel_times()
     eng0.profile(False)
+    if driver is not None:
+        kt["allgather"] = driver.collective_times()       # the step's collective, same (total ms, count) form
+        driver.profile_collective(False)
 
     if rank == 0:
         value = n_total * args.steps / el
         n_local = n_total // world if world > 1 else n_total
-        dom = max(((k, v) for k, v in kt.items() if v[1] > 0), key=lambda kv: kv[1][0], default=(None, (0, 0)))
+        dom = max(((k, v) for k, v in kt.items() if v[1] > 0 and k != "allgather"), key=lambda kv: kv[1][0], default=(None, (0, 0)))
         roof = None
         if dom[0] is not None:
             k, (ms, cnt) = dom
