@@ -224,7 +224,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
     c->plan_small = AMC_PLAN_SMALL;
     if (const char *e = getenv("AMC_PLAN_SMALL")) { const int v = atoi(e); if (v >= 0) c->plan_small = v; }
-    c->kin_send = c->kin_recv = c->kin_vpub = nullptr; c->kin_world = 0; c->kin_m = c->kin_cap = c->kin_block = 0; c->kin_lists = false;
+    c->kin_send = c->kin_recv = c->kin_vpub = nullptr; c->kin_world = 0; c->kin_m = c->kin_cap = c->kin_block = 0; c->kin_lists = false; c->kin_counts_clear = false;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;
     c->stream = nullptr;

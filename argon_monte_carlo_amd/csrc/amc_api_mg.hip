@@ -45,6 +45,7 @@ int amc_mg_exchange_view(amc_ctx *c, int world, void **send, void **recv, int64_
         AMC_HIP(c, hipMalloc((void **)&c->kin_send, sizeof(double) * (size_t)c->kin_block));
         AMC_HIP(c, hipMalloc((void **)&c->kin_recv, sizeof(double) * (size_t)c->kin_block * (size_t)world));
         c->kin_world = world;
+        c->kin_counts_clear = false;
     }
     *send = c->kin_send; *recv = c->kin_recv; *block = c->kin_block;
     return AMC_OK;

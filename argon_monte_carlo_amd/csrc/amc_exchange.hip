@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void k_kin_pack(kin_arrays S, long long lo, lo
 
 __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, int world, int rank, long long m, long long capb,
                                                     const double *__restrict__ recv, amc_grid G, amc_lists B,
-                                                    amc_dev_counters *cnt, int *__restrict__ slot_of)
+                                                    amc_dev_counters *cnt, int *__restrict__ slot_of,
+                                                    double *__restrict__ send)
 {
     const long long cap = capb * AMC_KIN_BANKS, per = m > cap ? m : cap;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // the all-gather that read `send` is over: its bank counters are cleared here for the next step's pack
+    if (idx < AMC_KIN_BANKS) send[3 * m + idx] = 0.0;
     if (idx >= (long long)world * per) return;
     const int r = (int)(idx / per);
     const long long u = idx % per;
@@ -122,14 +125,18 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
     if (!unpack) {
         c->B.epoch++;                           // a new set of lists: this shard now, the other shards at the unpack
         c->kin_lists = true;
-        hipError_t e = hipMemsetAsync(c->kin_send + 3 * m, 0, sizeof(double) * AMC_KIN_BANKS, c->stream);      // the banks' counters
-        if (e != hipSuccess) return e;
+        if (!c->kin_counts_clear) {             // (normally the previous step's unpack kernel has cleared the banks' counters)
+            hipError_t e = hipMemsetAsync(c->kin_send + 3 * m, 0, sizeof(double) * AMC_KIN_BANKS, c->stream);
+            if (e != hipSuccess) return e;
+        }
+        c->kin_counts_clear = false;
         hipLaunchKernelGGL(k_kin_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, S, (long long)c->lo,
                            (long long)c->hi, m, capb, c->kin_send, c->G, c->B, c->d_cnt);
     } else {
         const long long per = m > c->kin_cap ? m : c->kin_cap;
         hipLaunchKernelGGL(k_kin_unpack, dim3((unsigned)(((long long)world * per + 255) / 256)), dim3(256), 0, c->stream, S,
-                           (long long)c->n, world, rank, m, capb, c->kin_recv, c->G, c->B, c->d_cnt, c->W.slot_of);
+                           (long long)c->n, world, rank, m, capb, c->kin_recv, c->G, c->B, c->d_cnt, c->W.slot_of, c->kin_send);
+        c->kin_counts_clear = true;
     }
     amc_prof_end(c);
     return hipGetLastError();

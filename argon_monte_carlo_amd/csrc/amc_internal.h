@@ -155,6 +155,7 @@ struct amc_ctx {
     int kin_world;
     int64_t kin_m, kin_cap, kin_block;   // shard length (padded), capacity of the velocity-change list (all banks), 3m + banks + 4cap
     bool kin_lists;                // amc_mg_pack started this step's per-cell lists (the unpack completes them)
+    bool kin_counts_clear;         // the bank counters in kin_send are zero (cleared by the last unpack kernel)
 };
 
 int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
