@@ -168,7 +168,7 @@ void amc_destroy(amc_ctx *c)
                     c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
                     c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
                     c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
-                    c->W.ev_gen, c->W.ev_slot, c->W.wctl, c->W.deg, c->W.cand_done};
+                    c->W.ev_gen, c->W.ev_slot, c->W.wctl, c->W.adj_head, c->W.cand4, c->W.cand_done};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -271,7 +271,6 @@ int amc_create(amc_ctx **out, const amc_params *p)
         W.max_slots = (int)std::min<long long>(2 * mc, std::max<long long>(c->n, 2));
         W.max_edges = 4 * W.max_slots + 1024;
         W.max_hist = 8 * W.max_slots + 1024;
-        W.max_events = 8 * W.max_slots + 1024;
         CK(dalloc(&W.cand_i, (size_t)W.max_cand)); CK(dalloc(&W.cand_j, (size_t)W.max_cand));
         CK(dalloc(&W.cand_si, (size_t)W.max_cand)); CK(dalloc(&W.cand_sj, (size_t)W.max_cand));
         CK(dalloc(&W.cst, (size_t)22 * W.max_cand));
@@ -280,9 +279,11 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.wctl, 64));
         CK(hipMemsetAsync(W.wctl, 0, sizeof(int) * 64, c->stream));
         { amc_resolve_ctl z; memset(&z, 0, sizeof z); z.cur_round = 1; CK(hipMemcpyAsync(W.wctl, &z, sizeof z, hipMemcpyHostToDevice, c->stream)); CK(hipStreamSynchronize(c->stream)); }
-        CK(dalloc(&W.deg, n));
-        CK(hipMemsetAsync(W.deg, 0, sizeof(unsigned int) * std::max<size_t>(n, 1), c->stream));
+        CK(dalloc(&W.adj_head, n));
+        CK(hipMemsetAsync(W.adj_head, 0, sizeof(unsigned long long) * std::max<size_t>(n, 1), c->stream));
+        CK(dalloc(&W.cand4, (size_t)W.max_cand));
         CK(dalloc(&W.cand_done, (size_t)W.max_cand));
+        CK(hipMemsetAsync(W.cand_done, 0, (size_t)W.max_cand, c->stream));
         c->sweep_epoch = 0;
         CK(dalloc(&W.slot_of, n));
         CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));
@@ -297,10 +298,11 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_slot, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
         CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
         CK(dalloc(&W.hist, (size_t)W.max_hist)); CK(dalloc(&W.ov_next, (size_t)W.max_hist));
-        CK(dalloc(&W.ev_phase, (size_t)W.max_events)); CK(dalloc(&W.ev_i, (size_t)W.max_events));
-        CK(dalloc(&W.ev_j, (size_t)W.max_events)); CK(dalloc(&W.ev_which, (size_t)W.max_events));
-        CK(dalloc(&W.ev_cell, (size_t)W.max_events)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_events));
-        CK(dalloc(&W.ev_gen, (size_t)W.max_events)); CK(dalloc(&W.ev_slot, (size_t)W.max_events));
+        CK(dalloc(&W.ev_phase, (size_t)W.max_hist)); CK(dalloc(&W.ev_i, (size_t)W.max_hist));
+        CK(dalloc(&W.ev_j, (size_t)W.max_hist)); CK(dalloc(&W.ev_which, (size_t)W.max_hist));
+        CK(dalloc(&W.ev_cell, (size_t)W.max_hist)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_hist));
+        CK(dalloc(&W.ev_gen, (size_t)W.max_hist)); CK(dalloc(&W.ev_slot, (size_t)W.max_hist));
+        CK(hipMemsetAsync(W.ev_gen, 0, sizeof(int) * (size_t)W.max_hist, c->stream));
         // outputs
         long long mp = p->max_paths > 0 ? p->max_paths : (p->max_paths < 0 ? 0 : (1LL << 20));   // < 0: histograms only
         if (mp > 0x7fffffff) mp = 0x7fffffff;

@@ -1,0 +1,357 @@
+// amc_clusters.hip — the wide half of the ordered p-p resolve: every SMALL connected component of the candidate graph is
+// emulated here, spread over the whole chip, and validates its own new positions; the single ordered workgroup
+// (k_resolve, amc_resolve.hip) is left with what is entangled beyond that — components larger than CW_MAXM particles,
+// and clusters whose validation found an outsider (merge, re-emulate, re-validate) — plus the commit of a small sweep.
+//
+// Reference semantics kept (Pore:168-241 in-place i>j order, Pore:522-530 group / cell order, Cube:231-238): a cluster
+// is emulated literally, restricted to its members, exactly as the ordered workgroup would do it (rs_emulate_pair /
+// rs_emulate_coop / rs_emulate_generic are shared); what is added here is only WHO does it and WHEN it is validated.
+//
+//   1. one lane per candidate k.  It reads the candidate record and the graph heads of its two particles (adjacency
+//      lists built by the detect kernel, amc_grid.hip).  Both lists hold only k  =>  isolated pair: the lane owns it.
+//      Otherwise the lane walks the component; it gives up as soon as it meets a candidate with a lower index (the
+//      lowest candidate's lane owns the component) or when the component exceeds CW_MAXM particles / CW_MAXC candidates
+//      (left to the ordered workgroup: nobody marks its candidates done).
+//   2. slots and history entries for everything the wave owns are reserved with ONE pair of counter increments
+//      (history: one entry pair per candidate; a cluster that hits more often than it has candidates takes the extra
+//      pairs from the counter and is flagged for the ordered workgroup, which redoes it — rare).
+//   3. isolated pairs are emulated by their lanes in registers; larger clusters one after the other by the whole wave
+//      (working set in LDS, members in ascending particle index).
+//   4. publish-then-probe: every new position is first pushed on the overlay list of its grid cell (write-through
+//      record, then a compare-and-swap on the list head — a reader never meets a half-linked entry), and only after
+//      ALL pushes of the wave have returned are the positions probed: against the pre-sweep positions of everything
+//      outside the cluster (the detection grid's lists) and against the other clusters' new positions (the overlay
+//      lists, read at agent scope).  Two clusters whose new positions conflict are both pushed before either probes
+//      or one probes after the other's push — at least one of them sees the other.  A hit becomes a merge edge (and a
+//      slot for a so far uninvolved particle) exactly like in the ordered workgroup's validation; the ordered workgroup
+//      then merges, re-emulates from the untouched pre-sweep state and validates again.
+//
+// Bound: latency (a chain of ~8 dependent memory round trips per candidate), which is why the candidates are spread as
+// thinly as the launch allows: CW_BLOCKS one-wave workgroups, ceil(ncand / CW_BLOCKS) candidates per wave.
+#include "amc_resolve_dev.h"
+
+#define CW_MAXM 16          // particles of a component handled here
+#define CW_MAXC 24          // its candidates
+#define CW_ITEMS 192        // new positions one wave can publish + probe per pass (two per hit)
+#define CW_BLOCKS 512
+
+AMC_DEV int cw_adj_head(const amc_resolve_ws &W, unsigned int epoch, int p)
+{
+    const unsigned long long v = W.adj_head[p];
+    return ((unsigned int)(v >> 32) == epoch) ? (int)(unsigned int)(v & 0xffffffffULL) : -1;
+}
+
+// two wave-wide reservations, both counter increments in flight together; every lane of the wave calls
+AMC_DEV void cw_reserve2(int *ca, int na, int *cb, int nb, int &base_a, int &base_b)
+{
+    const int lane = threadIdx.x & 63;
+    int ia = na, ib = nb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
+        if (lane >= o) { ia += ta; ib += tb; }
+    }
+    const int tot_a = __shfl(ia, 63, 64), tot_b = __shfl(ib, 63, 64);
+    int ba = 0, bb = 0;
+    if (lane == 0) {
+        if (tot_a) ba = atomicAdd(ca, tot_a);
+        if (tot_b) bb = atomicAdd(cb, tot_b);
+    }
+    base_a = __shfl(ba, 0, 64) + ia - na;
+    base_b = __shfl(bb, 0, 64) + ib - nb;
+}
+
+// a particle outside every cluster gets a slot (it joins a cluster in the ordered workgroup's next round)
+AMC_DEV void cw_claim(const amc_resolve_ws &W, rs_shared *wc, int idx)
+{
+    const int old = atomicCAS(&W.slot_of[idx], -1, -2);
+    if (old != -1) return;
+    const int s = atomicAdd(&wc->nslots, 1);
+    if (s < W.max_slots) {
+        W.sl_p[s] = idx; W.sl_label[s] = s; W.sl_moved[s] = 0; W.sl_gen[s] = 0;
+        atomicAnd(&W.sl_hits[s], 0);
+        W.slot_of[idx] = s;
+    } else {
+        wc->ovf = 1;
+        W.slot_of[idx] = -1;
+    }
+}
+
+AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label)
+{
+    W.slot_of[p] = s; W.sl_p[s] = p; W.sl_label[s] = label; W.sl_moved[s] = 0; W.sl_gen[s] = 1;
+    atomicAnd(&W.sl_hits[s], 0);        // (an atomic, like the increments that follow)
+}
+
+AMC_DEV double4 cw_load_hist(const amc_resolve_ws &W, int h)
+{
+    const double *d = (const double *)&W.hist[h];
+    double4 r;
+    r.x = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.y = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.z = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.w = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+
+struct cw_lds {
+    int mem[64][CW_MAXM];       // per owner lane: the particles of its component (sorted ascending before use)
+    int cnd[64][CW_MAXC];       // and its candidates
+    int nm[64], nc[64], base[64], hb[64], he[64], it0[64];   // members, candidates, first slot, reserved entries [hb, he), first work item
+    cw_item item[CW_ITEMS];
+    int next[CW_ITEMS];         // overlay `next` of every published item (own entries are stepped over without a load)
+    int nitems, hnext, unval;
+    double pool_d[10][CW_MAXM];
+    int pool_tmp[CW_MAXM], pool_pidx[CW_MAXM], pool_slot[CW_MAXM];
+    uint8_t pool_flag[CW_MAXM], pool_moved[CW_MAXM];
+};
+
+// probe of one published position: everything outside its cluster within the (inflated) collision range is a merge edge
+AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, double cr2i)
+{
+    const amc_resolve_ws &W = A.W;
+    const int own = me.own, nm = L.nm[own], base = L.base[own], hb = L.hb[own], he = L.he[own], it0 = L.it0[own];
+    const double x = me.x, y = me.y, z = me.z;
+    int c_lo[4], c_hi[4], lh[8], ovh[8];
+    const int ncell = amc_grid_box_ranges(A.G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        lh[2 * k] = lh[2 * k + 1] = -1; ovh[2 * k] = ovh[2 * k + 1] = -1;
+        if (k < ncell) {
+            lh[2 * k] = amc_list_head(A.B, c_lo[k]);
+            ovh[2 * k] = __hip_atomic_load(&W.ov_head[c_lo[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c_hi[k] != c_lo[k]) {
+                lh[2 * k + 1] = amc_list_head(A.B, c_hi[k]);
+                ovh[2 * k + 1] = __hip_atomic_load(&W.ov_head[c_hi[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // entries of my own cluster are stepped over through the `next` values its pushes returned (LDS), without a load
+    auto skip_own = [&](int h2) {
+        while (h2 >= hb && h2 < he) h2 = L.next[it0 + (h2 - hb)];
+        return h2;
+    };
+    auto member = [&](int idx) {
+        for (int m = 0; m < nm; m++)
+            if (L.mem[own][m] == idx) return true;
+        return false;
+    };
+    auto grid_entry = [&](int idx, const double4 &r) {
+        const double ax = r.x - x, ay = r.y - y, az = r.z - z;
+        if (!(ax * ax + ay * ay + az * az < cr2i)) return;
+        if (member(idx)) return;
+        if (cw_adj_head(W, A.sweep_epoch, idx) < 0) cw_claim(W, wc, idx);   // in no candidate: give it a slot now
+        rs_add_edge(W, wc, me.p, idx);
+    };
+    auto overlay_entry = [&](const double4 &o) {
+        const int s2 = rs_hist_slot(o);
+        if (s2 >= base && s2 < base + nm) return;
+        if (rs_hist_gen(o) == 0) return;
+        const double ax = o.x - x, ay = o.y - y, az = o.z - z;
+        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, wc, me.p, -(s2 + 2));    // (the other end as a slot)
+    };
+    // first element of every list before any is examined (the probe is a chain of dependent round trips)
+    double4 r0[8], o0[8];
+    int on0[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (lh[k] >= 0) r0[k] = A.B.rec[lh[k]];
+        ovh[k] = skip_own(ovh[k]);
+        if (ovh[k] >= 0) {
+            o0[k] = cw_load_hist(W, ovh[k]);
+            on0[k] = __hip_atomic_load(&W.ov_next[ovh[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (lh[k] >= 0) {
+            grid_entry(lh[k], r0[k]);
+            for (int q = amc_rec_next(r0[k]); q >= 0;) {
+                const double4 r = A.B.rec[q];
+                grid_entry(q, r);
+                q = amc_rec_next(r);
+            }
+        }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (ovh[k] >= 0) {
+            overlay_entry(o0[k]);
+            for (int h2 = skip_own(on0[k]); h2 >= 0;) {
+                const double4 o = cw_load_hist(W, h2);
+                const int nx = __hip_atomic_load(&W.ov_next[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                overlay_entry(o);
+                h2 = skip_own(nx);
+            }
+        }
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
+{
+    const amc_resolve_ws &W = A.W;
+    rs_shared *wc = (rs_shared *)W.wctl;
+    __shared__ cw_lds L;
+    const int lane = threadIdx.x;
+    int ncand = (int)A.O.cnt->cand_count;
+    if (ncand > W.max_cand) ncand = W.max_cand;
+    if (blockIdx.x == 0 && lane == 0) wc->active = 1;
+    if (ncand == 0) return;
+    const int nwaves = gridDim.x;
+    int per = (ncand + nwaves - 1) / nwaves;
+    if (per > 64) per = 64;
+    const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
+    rs_work K;
+    K.x = L.pool_d[0]; K.y = L.pool_d[1]; K.z = L.pool_d[2]; K.vx = L.pool_d[3]; K.vy = L.pool_d[4]; K.vz = L.pool_d[5];
+    K.d = L.pool_d[6]; K.dx = L.pool_d[7]; K.dy = L.pool_d[8]; K.dz = L.pool_d[9];
+    K.tmp = L.pool_tmp; K.pidx = L.pool_pidx; K.slot = L.pool_slot; K.flag = L.pool_flag; K.moved = L.pool_moved;
+
+    for (int k0 = blockIdx.x * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
+        const int k = k0 + lane;
+        const bool valid = lane < per && k < ncand;
+        if (lane == 0) L.nitems = 0;
+        // ---- 1. my candidate and the graph around it -----------------------------------------------------------------
+        int4 c4 = make_int4(0, 0, -1, -1);
+        int head_i = -1, head_j = -1;
+        if (valid) {
+            c4 = W.cand4[k];
+            head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
+            head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
+        }
+        const bool iso = valid && head_i == k && c4.z < 0 && head_j == k && c4.w < 0;
+        bool owner = valid && !iso;
+        int nm = 2, nc = 1;
+        int *mem = L.mem[lane], *cnd = L.cnd[lane];
+        mem[0] = c4.y; mem[1] = c4.x; cnd[0] = k;
+        if (owner) {
+            for (int cur = 0; cur < nm && owner; cur++) {
+                const int p = mem[cur];
+                int c = cur == 0 ? head_j : (cur == 1 ? head_i : cw_adj_head(W, A.sweep_epoch, p));
+                while (c >= 0) {
+                    if (c < k) { owner = false; break; }            // the component belongs to a lower candidate's lane
+                    const int4 r = (c == k) ? c4 : W.cand4[c];
+                    const int q = (r.x == p) ? r.y : r.x;
+                    const int nx = (r.x == p) ? r.z : r.w;
+                    bool seen = false;
+                    for (int e = 0; e < nc; e++) seen |= cnd[e] == c;
+                    if (!seen) {
+                        if (nc == CW_MAXC) { owner = false; break; }       // too large for this kernel
+                        cnd[nc++] = c;
+                    }
+                    seen = false;
+                    for (int e = 0; e < nm; e++) seen |= mem[e] == q;
+                    if (!seen) {
+                        if (nm == CW_MAXM) { owner = false; break; }
+                        mem[nm++] = q;
+                    }
+                    c = nx;
+                }
+            }
+            if (owner)                                              // members in ascending particle index (Pore:538)
+                for (int a = 1; a < nm; a++) {
+                    const int v = mem[a];
+                    int b = a - 1;
+                    while (b >= 0 && mem[b] > v) { mem[b + 1] = mem[b]; b--; }
+                    mem[b + 1] = v;
+                }
+        }
+        // ---- 2. slots and history pairs for everything this wave owns ---------------------------------------------------
+        const int want_s = iso ? 2 : (owner ? nm : 0), want_h = iso ? 2 : (owner ? 2 * nc : 0);
+        int sbase, hbase;
+        cw_reserve2(&wc->nslots, want_s, &wc->nhist, want_h, sbase, hbase);
+        bool take = iso || owner;
+        if (take && (sbase + want_s > W.max_slots || hbase + want_h > W.max_hist)) { wc->ovf = 1; take = false; }
+        L.nm[lane] = nm; L.nc[lane] = nc; L.base[lane] = sbase; L.hb[lane] = hbase; L.he[lane] = hbase + (take ? want_h : 0);
+        L.it0[lane] = -1;
+        if (take)
+            for (int e = hbase; e < hbase + want_h; e++) W.ev_gen[e] = 0;       // "no event" until a hit stores one
+        {
+            const int ncl = __popcll(__ballot(take));
+            if (lane == 0 && ncl) atomicAdd(&wc->nclusters, ncl);
+        }
+        __syncthreads();
+        // ---- 3a. isolated pairs: both particles in registers ------------------------------------------------------------------
+        if (iso && take) {
+            const int pj = c4.y, pi = c4.x, sj = sbase, si = sbase + 1;
+            cw_init_slot(W, sj, pj, sj);
+            cw_init_slot(W, si, pi, sj);
+            W.cand_sj[k] = sj; W.cand_si[k] = si; W.cand_done[k] = 1;
+            int pre_next = hbase, unval = 0;
+            rs_wide wd;
+            wd.pre_next = &pre_next; wd.pre_end = hbase + 2; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+            wd.own = lane; wd.it0 = &L.it0[lane]; wd.unval = &unval;
+            rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
+            if (unval) rs_add_edge(W, wc, pi, pi);          // (self edge: the ordered workgroup redoes this cluster)
+        }
+        // ---- 3b. larger clusters, one after the other by the whole wave ----------------------------------------------------------
+        unsigned long long owners = __ballot(owner && take);
+        while (owners) {
+            const int src = __ffsll((long long)owners) - 1;
+            owners &= owners - 1;
+            const int m = L.nm[src], ncs = L.nc[src], base = L.base[src];
+            if (lane == 0) { L.hnext = L.hb[src]; L.unval = 0; }
+            if (lane < m) {
+                const int p = L.mem[src][lane];
+                const amc_particle q = rs_load_particle(A.S, p);
+                rs_store_work(K, lane, q);
+                K.moved[lane] = 0; K.pidx[lane] = p; K.slot[lane] = base + lane;
+                cw_init_slot(W, base + lane, p, base);
+            }
+            for (int e = lane; e < ncs; e += 64) {
+                const int c = L.cnd[src][e];
+                const int pi = W.cand_i[c], pj = W.cand_j[c];
+                int ai = 0, aj = 0;
+                for (int t = 0; t < m; t++) { if (L.mem[src][t] == pi) ai = t; if (L.mem[src][t] == pj) aj = t; }
+                W.cand_si[c] = base + ai; W.cand_sj[c] = base + aj; W.cand_done[c] = 1;
+            }
+            __syncthreads();
+            rs_wide wd;
+            wd.pre_next = &L.hnext; wd.pre_end = L.he[src]; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+            wd.own = src; wd.it0 = &L.it0[src]; wd.unval = &L.unval;
+            if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
+            else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
+            __syncthreads();
+            if (lane < m && K.moved[lane]) rs_store_slot(W, K.slot[lane], rs_load_work(K, lane));
+            if (lane == 0 && L.unval) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);
+            __syncthreads();
+        }
+        // ---- 4. publish every new position, then probe them ---------------------------------------------------------------------
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the history records (write-through stores) have left
+        const int nit = L.nitems < CW_ITEMS ? L.nitems : CW_ITEMS;
+        for (int t0 = 0; t0 < nit; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nit) L.next[t] = -1;
+            if (t < nit && !L.item[t].pad) {
+                const cw_item it = L.item[t];
+                int cx, cy, cz;
+                amc_grid_coords(A.G, it.x, it.y, it.z, cx, cy, cz);
+                const int cell = amc_grid_cell(A.G, cx, cy, cz, nullptr);
+                int expected = -1;                              // (the record was stored with next = -1)
+                for (;;) {
+                    const int old = atomicCAS(&W.ov_head[cell], expected, it.h);
+                    if (old == expected) break;
+                    expected = old;
+                    __hip_atomic_store(&W.ov_next[it.h], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                L.next[t] = expected;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every push of this wave has returned
+        __syncthreads();
+        for (int t0 = 0; t0 < nit; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nit && !L.item[t].pad) cw_probe(A, wc, L, L.item[t], cr2i);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
+{
+    switch (c->P.geometry) {
+    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3(CW_BLOCKS), dim3(64), 0, c->stream, A); break;
+    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3(CW_BLOCKS), dim3(64), 0, c->stream, A); break;
+    }
+    return hipGetLastError();
+}

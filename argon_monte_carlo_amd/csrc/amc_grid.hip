@@ -38,34 +38,35 @@ __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x,
 // A candidate is stored as (i, j) with i > j plus a copy of both particles' state in a SoA table (cst[e][k], e = 0..10
 // particle j, 11..21 particle i): the single-workgroup resolve kernel then reads coalesced rows instead of issuing
 // 22 scattered loads per pair from one CU.  Returns the candidate's slot (or -1 on overflow).
-// number of candidates that touch particle p in this sweep, saturating at 3, tagged with the sweep's epoch so that the
-// table is never cleared: the wide pair kernel (amc_resolve.hip) takes the pairs whose endpoints both have degree one
-struct amc_degrees {
-    unsigned int *deg;
+// The candidate graph: every pushed pair is linked into the candidate lists of both its particles with one 64-bit
+// exchange each (head tagged with the sweep's epoch, so the table is never cleared).  The wide cluster kernel
+// (amc_clusters.hip) walks these lists: a pair whose two particles appear in no other candidate is emulated by one lane,
+// a larger connected component by the wave of its lowest candidate.
+struct amc_adj {
+    unsigned long long *head;   // [n]   nullptr: the graph is not needed (all-pairs mode)
+    int4 *rec;                  // [max_cand]
+    uint8_t *done;              // [max_cand]
     unsigned int epoch;
 };
-AMC_DEV void amc_degree_inc(const amc_degrees &D, int p)
-{
-    if (!D.deg) return;
-    unsigned int old = D.deg[p];
-    for (;;) {
-        const unsigned int c = (old >> 2) == D.epoch ? (old & 3u) : 0u;
-        const unsigned int nw = (D.epoch << 2) | (c < 3u ? c + 1u : 3u);
-        const unsigned int seen = atomicCAS(&D.deg[p], old, nw);
-        if (seen == old) break;
-        old = seen;
-    }
-}
 
 AMC_DEV int amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                               const amc_degrees &D)
+                               const amc_adj &D)
 {
     const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
     if (k < (unsigned)max_cand) {
-        cand_i[k] = a > b ? a : b;
-        cand_j[k] = a > b ? b : a;
-        amc_degree_inc(D, a);
-        amc_degree_inc(D, b);
+        const int hi = a > b ? a : b, lo = a > b ? b : a;
+        cand_i[k] = hi;
+        cand_j[k] = lo;
+        if (D.head) {
+            const unsigned long long mine = ((unsigned long long)D.epoch << 32) | (unsigned long long)k;
+            const unsigned long long oi = atomicExch(&D.head[hi], mine), oj = atomicExch(&D.head[lo], mine);
+            int4 r;
+            r.x = hi; r.y = lo;
+            r.z = ((unsigned int)(oi >> 32) == D.epoch) ? (int)(unsigned int)(oi & 0xffffffffULL) : -1;
+            r.w = ((unsigned int)(oj >> 32) == D.epoch) ? (int)(unsigned int)(oj & 0xffffffffULL) : -1;
+            D.rec[k] = r;
+            D.done[k] = 0;
+        }
         return (int)k;
     }
     atomicOr(&cnt->flags, 1ULL);
@@ -106,7 +107,7 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
 __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
                                                       int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                                                      amc_state S, double *cst, amc_degrees D)
+                                                      amc_state S, double *cst, amc_adj D)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ z, int n, int ntiles, double cr2i,
                                                           int *cand_i, int *cand_j, int max_cand,
-                                                          amc_dev_counters *cnt, amc_state S, double *cst, amc_degrees D)
+                                                          amc_dev_counters *cnt, amc_state S, double *cst, amc_adj D)
 {
     // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -244,13 +245,14 @@ hipError_t amc_launch_detect(amc_ctx *c)
     const long long n = c->n;
     if (n <= 0) return hipSuccess;
     const double cr2i = c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE;
-    amc_degrees D;
+    amc_adj D;
     c->sweep_epoch = (c->sweep_epoch + 1u) & 0x3fffffffu;
     if (c->sweep_epoch == 0u) c->sweep_epoch = 1u;      // (0 is the value of the zero-initialised table)
     // launch plan of this sweep from the candidate count of the most recent sweep the host has seen (a word the resolve
-    // kernel writes into host-mapped memory; it may lag by a step): only the large plan uses the degrees
+    // kernel writes into host-mapped memory; it may lag by a step): a small sweep is committed by the ordered
+    // workgroup itself, a large one by the wide commit kernel
     c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
-    D.deg = c->plan_split ? c->W.deg : nullptr; D.epoch = c->sweep_epoch;
+    D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.done = c->W.cand_done; D.epoch = c->sweep_epoch;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);

@@ -70,15 +70,20 @@ struct amc_resolve_ws {
     double4 *hist;            // position history of the sweep: (x, y, z, slot | round << 32) per new position
     int max_hist;
     int *ov_head, *ov_next;   // overlay lists of history entries per grid cell ([ncells], [max_hist])
-    // events of the current round (completed paths, emitted at commit)
+    // completed paths found by the emulations, emitted at commit.  Events share the index space of the history: a hit
+    // owns the entry pair (h, h + 1) — h for particle j, h + 1 for particle i — and its (at most two) events sit at the
+    // same two indices; ev_gen == 0 marks "no event" ([max_hist] each)
     int *ev_phase, *ev_i, *ev_j, *ev_which;
     long long *ev_cell;
-    double *ev_val;           // [max_events][4]
-    int max_events;
+    double *ev_val;           // [max_hist][4]
     int *ctl;                 // rs_shared in global memory: hand-over between the resolve kernels
-    int *wctl;                // rs_shared of the wide pair kernel (counters it advanced before the ordered workgroup starts)
-    unsigned int *deg;        // [n] candidates touching the particle in the current sweep: (sweep epoch << 2) | min(count, 3)
-    uint8_t *cand_done;       // [max_cand] pair already emulated by the wide pair kernel
+    int *wctl;                // rs_shared of the wide cluster kernel (counters it advanced before the ordered workgroup starts)
+    // candidate graph, built by the detect kernel with one 64-bit exchange per endpoint (no clearing: epoch tags):
+    //   adj_head[p] = (sweep epoch << 32) | last candidate pushed that touches particle p
+    //   cand4[k]    = (i, j, next candidate in i's list, next candidate in j's list)
+    unsigned long long *adj_head;   // [n]
+    int4 *cand4;              // [max_cand]
+    uint8_t *cand_done;       // [max_cand] candidate belongs to a cluster the wide kernel emulated (cleared by detect)
     double *cst;              // [22][max_cand] state of both particles of every candidate, gathered by detect
 };
 

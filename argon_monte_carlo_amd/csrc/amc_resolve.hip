@@ -21,12 +21,15 @@
 //      reference computes;
 //   4. commit: scratch state -> particle arrays, completed paths -> histogram / record buffer, counters.
 //
-// The ordered logic runs in ONE 512-thread workgroup (phases separated by __syncthreads, counters in LDS): the data
-// set is a few hundred pairs, so the cost is latency, not throughput.  Everything that is scattered memory traffic
-// is kept off that single CU: detect gathers the candidates' state into a SoA table (coalesced reads here), and for
-// large sweeps (> 430 candidates) the isolated pairs are emulated by a wide kernel first (k_pairs_wide), the first
-// round's validation probes and the commit scatter are separate wide kernels, and only the entangled remainder and
-// the later rounds stay in the workgroup.  A multi-particle cluster is emulated by a whole wave (rs_emulate_coop).
+// Who does what (grid mode): steps 1-3 of the FIRST round run wide, over the whole chip, in k_clusters_wide
+// (amc_clusters.hip) for every connected component of up to 16 particles — each validates its own new positions there.
+// What is left for the ONE 512-thread workgroup of this file (phases separated by __syncthreads, counters in LDS; its
+// cost is latency, not throughput) is the entangled remainder: components too large for the wide kernel (claim,
+// label, emulate, validate as below), the later rounds after a validation found an outsider (merge along the new
+// edges, re-emulate only the touched clusters from the untouched pre-sweep state, validate again), and the commit of
+// a small sweep (a large one is committed by the wide k_commit).  When the wide kernel left nothing and found nothing
+// — the usual case — this kernel is the commit alone.  Without a detection grid (single cells, N <= 4096: MODE 2)
+// everything, brute-force validation included, happens here.
 #include "amc_resolve_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
@@ -41,16 +44,18 @@
 #define RS_NS 6144             // slot labels / sizes / dirty flags kept in LDS (54 KB)
 #define RS_LAY 4096            // ints of the grid's layer tables kept in LDS
 
-// MODE 0: first round only (claim, label, emulate), validation + commit are the wide kernels that follow
-// MODE 1: continuation: if the wide validation found merges, run the remaining rounds (validation in-kernel)
-// MODE 2: everything in one kernel incl. brute-force validation and commit (no detection grid: single cells, small N)
+// MODE 0: grid mode, after k_clusters_wide (A.wide_plan): the remainder, the later rounds and — when the host launched
+//         only this kernel after it (A.force_mono, small sweeps) — the commit; else k_commit follows
+// MODE 2: no detection grid (single cells, small N): everything in one kernel incl. brute-force validation and commit
 template <int GEOM, int MODE>
 __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     __shared__ rs_shared sh;
-    __shared__ int wide_ns;             // slots made by the wide pair kernel in this sweep, -1 if it did not run
-    __shared__ int wide_nh;             // history entries it made (already in the overlay lists)
+    __shared__ int wide_ns;             // slots made by the wide cluster kernel in this sweep, -1 if it did not run
+    __shared__ int wide_nh;             // history entries it made (published and validated there)
+    __shared__ int wide_dirty;          // its validation found merge edges
+    __shared__ int s_left;              // candidates it left to this kernel
     __shared__ int s_heads[64], s_nheads;   // first member of every multi-particle cluster when all waves share them
     __shared__ unsigned long long lds_keys[RS_SORT_LDS];
     __shared__ double pool_d[10][RS_POOL];
@@ -63,65 +68,66 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     const int tid = threadIdx.x;
     amc_dev_counters *cnt = A.O.cnt;
     rs_shared *ctl = (rs_shared *)W.ctl;
-    int ncand;
-    if (threadIdx.x == 0) { wide_ns = -1; wide_nh = 0; }
-    if (MODE == 1) {
-        if (tid == 0) sh = *ctl;
-        __syncthreads();
-        if (!sh.active || !sh.dirty || sh.ovf) return;      // the first round validated (or nothing to do)
-        ncand = sh.ncand;
-    } else {
-        ncand = (int)cnt->cand_count;
-        if (ncand > W.max_cand) ncand = W.max_cand;
-        __syncthreads();
-        if (tid == 0) {
-            // what the wide pair kernel did before this one (slots, history, events of the isolated pairs); zero if it
-            // did not run.  Its control block is re-armed for the next sweep.
-            sh.nslots = 0; sh.nhist = 0; sh.nev = 0; sh.nfp = 0; sh.ovf = 0;
-            if (A.wide_plan) {
-                rs_shared *wc = (rs_shared *)W.wctl;
-                sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
-                sh.nhist = wc->nhist; sh.nev = wc->nev; sh.nfp = wc->nfp; sh.ovf = wc->ovf;
-                wide_ns = wc->active ? sh.nslots : -1;             // (>= 0: the wide kernel ran, W.cand_done is valid)
-                wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-                wc->nslots = 0; wc->nhist = 0; wc->nev = 0; wc->nfp = 0; wc->ovf = 0; wc->active = 0; wc->cur_round = 1;
-            }
-            sh.nslots0 = 0;
-            sh.nedges = 0; sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
-            sh.nclusters = 0; sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
-            sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0;
-            sh.lazy_ns = 0;         // the streaming pass before this sweep consumed the previous sweep's deferred results
-            cnt->cand_count = 0;
-            if (A.host_ncand) *A.host_ncand = ncand;
-            if (ncand == 0) *ctl = sh;
+    int ncand = (int)cnt->cand_count;
+    if (ncand > W.max_cand) ncand = W.max_cand;
+    if (tid == 0) {
+        // what the wide cluster kernel did before this one (slots, history, events, merge edges); zero if it did not
+        // run.  Its control block is re-armed for the next sweep.
+        wide_ns = -1; wide_nh = 0; wide_dirty = 0; s_left = 0;
+        sh.nslots = 0; sh.nhist = 0; sh.nev = 0; sh.nfp = 0; sh.ovf = 0; sh.nedges = 0; sh.nclusters = 0;
+        if (MODE == 0 && A.wide_plan) {
+            rs_shared *wc = (rs_shared *)W.wctl;
+            sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
+            sh.nhist = wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges; sh.nclusters = wc->nclusters;
+            wide_dirty = wc->dirty;
+            wide_ns = wc->active ? sh.nslots : -1;              // (>= 0: the wide kernel ran, W.cand_done is valid)
+            wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+            wc->nslots = 0; wc->nhist = 0; wc->nedges = 0; wc->nfp = 0; wc->ovf = 0; wc->dirty = 0; wc->nclusters = 0;
+            wc->active = 0; wc->cur_round = 1;
         }
-        __syncthreads();
-        if (ncand == 0) return;     // uniform: nothing to resolve this sweep
+        sh.nslots0 = 0;
+        sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
+        sh.ncomplex = 0; sh.rounds = 0; sh.ncand = ncand;
+        sh.active = ncand > 0; sh.ok = 1; sh.edges_done = 0; sh.hist_begin = 0; sh.cur_round = 0;
+        sh.lazy_ns = 0;         // the streaming pass before this sweep consumed the previous sweep's deferred results
+        cnt->cand_count = 0;
+        if (A.host_ncand) *A.host_ncand = ncand;
+        if (ncand == 0) *ctl = sh;
     }
+    __syncthreads();
+    if (ncand == 0) return;     // uniform: nothing to resolve this sweep
 
-    // MODE 2 always, MODE 0 for small sweeps: validation and commit in this kernel (the wide kernels then find
-    // ctl.active == 0 and exit); large sweeps hand over after the first round
-    const bool mono = (MODE == 2) || (MODE == 0 && (A.force_mono || ncand <= A.plan_small));
+    const bool wide = wide_ns >= 0;
+    const bool mono = (MODE == 2) || A.force_mono;      // commit in this kernel
+    {
+        int mine = 0;
+        for (int k = tid; k < ncand; k += RS_T) mine += !(wide && W.cand_done[k]);
+        if (mine) atomicAdd(&s_left, mine);
+    }
+    __syncthreads();
+    const int nleft = s_left;
+    // nothing left and nothing found by the wide kernel's validation: the sweep is resolved, only the commit remains
+    const bool resolved = wide && nleft == 0 && !wide_dirty;
+    RS_STAMP(0);
+
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
     V.p = W.sl_p;
     unsigned char *vdirty;
     // (the slot arrays in global memory hold W.max_slots entries: labels in LDS must not let validation claim more)
-    if ((MODE == 1 ? sh.nslots : 2 * ncand) + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS < W.max_slots ? RS_NS : W.max_slots; vdirty = s_dirty; }
+    if ((wide ? wide_ns : 0) + 2 * nleft + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS < W.max_slots ? RS_NS : W.max_slots; vdirty = s_dirty; }
     else { V.label = W.sl_label; V.size = W.sl_tmp; V.cap = W.max_slots; vdirty = W.sl_dirty; }
-    // grid layer tables -> LDS (every validation probe reads them)
     amc_grid G = A.G;
-    if ((MODE != 0 || mono) && !A.allpairs && 3 * G.gz <= RS_LAY) {
-        for (int k = tid; k < 3 * G.gz; k += RS_T) s_lay[k] = A.G.lay_lo[k];     // the three tables are contiguous
-        G.lay_lo = s_lay; G.lay_n = s_lay + G.gz; G.lay_off = s_lay + 2 * G.gz;
-    }
-    __syncthreads();
-
-    if (MODE != 1) {
-        // ---- slots for the candidate endpoints; candidates become slot pairs -------------------------------------------
-        const bool wide = wide_ns >= 0;
+    int rounds = 0;
+    if (!resolved) {
+        // grid layer tables -> LDS (every validation probe reads them)
+        if (!A.allpairs && 3 * G.gz <= RS_LAY) {
+            for (int k = tid; k < 3 * G.gz; k += RS_T) s_lay[k] = A.G.lay_lo[k];     // the three tables are contiguous
+            G.lay_lo = s_lay; G.lay_n = s_lay + G.gz; G.lay_off = s_lay + 2 * G.gz;
+        }
+        // ---- slots for the endpoints of the candidates that are left; candidates become slot pairs ----------------------
         for (int k = tid; k < ncand; k += RS_T) {
-            if (wide && W.cand_done[k]) continue;           // isolated pair: slots, state and history exist already
+            if (wide && W.cand_done[k]) continue;           // its cluster was emulated wide: slots, state and history exist
             rs_claim_slot(W, &sh, V.cap, W.cand_i[k]);
             rs_claim_slot(W, &sh, V.cap, W.cand_j[k]);
         }
@@ -133,49 +139,43 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         __syncthreads();
     }
-    RS_STAMP(0);
+    RS_STAMP(1);
 
-    int rounds = sh.rounds;
-    int edges_done = sh.edges_done;     // edges [0, edges_done) already hold slot ids
     int ns_lab = 0;                     // slots that carry a label of the previous round
-    if (MODE == 1) {
-        // continuation: the labels of the round(s) before are in global memory (written at the hand-over)
-        ns_lab = sh.nslots0 < V.cap ? sh.nslots0 : V.cap;
-        if (V.label != W.sl_label)
-            for (int s = tid; s < ns_lab; s += RS_T) V.label[s] = W.sl_label[s];
-        __syncthreads();
-    }
-    for (;;) {
+    int edges_conv = 0;                 // edges [0, edges_conv) hold slot ids
+    int edges_merged = 0;               // edges [0, edges_merged) have been merged into the labels
+    while (!resolved) {
         rounds++;
         const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
         const int nedges = sh.nedges < W.max_edges ? sh.nedges : W.max_edges;
         __syncthreads();
-        // ---- per-round reset; new merge edges: particle ids -> slot ids -------------------------------------------------
+        // ---- per-round reset; new merge edges: particle ids (or encoded slots) -> slot ids -----------------------------------
         const bool first = (rounds == 1);
         for (int s = tid; s < ns; s += RS_T) {
-            if (first || s >= ns_lab) V.label[s] = s;       // later rounds keep the previous round's labels
+            if (first) {
+                // slots of the wide kernel carry the labels it wrote (first slot of the cluster) and are NOT emulated
+                // again in this round; everything claimed here starts as its own cluster and is
+                if (V.label != W.sl_label || s >= wide_ns) V.label[s] = (s < wide_ns) ? W.sl_label[s] : s;
+            } else if (s >= ns_lab) {
+                V.label[s] = s;                             // claimed by the previous validation
+            }
             V.size[s] = first ? 0 : s;                      // (later rounds: parent map of the cluster merges, see below)
-            vdirty[s] = first;                              // round 1 emulates everything; later rounds only what the new edges touch
+            vdirty[s] = first && s >= wide_ns;              // later rounds: only what the new edges touch
         }
-        for (int k = edges_done + tid; k < nedges; k += RS_T) {
-            W.edge_a[k] = W.slot_of[W.edge_a[k]];
-            W.edge_b[k] = W.slot_of[W.edge_b[k]];
+        for (int k = edges_conv + tid; k < nedges; k += RS_T) {
+            const int ea = W.edge_a[k], eb = W.edge_b[k];
+            W.edge_a[k] = ea < -1 ? -(ea + 2) : W.slot_of[ea];
+            W.edge_b[k] = eb < -1 ? -(eb + 2) : W.slot_of[eb];
         }
-        const int edges_new = edges_done;
-        edges_done = nedges;
-        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? 0 : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }   // (round 1 also validates what the wide pair kernel produced)
+        edges_conv = nedges;
+        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }
         __syncthreads();
         if (first) {
-            // ---- connected components by label propagation (label = lowest slot id of the cluster); the pairs the wide
-            // kernel emulated are isolated by construction: their label is known without propagation ----------------------
-            const bool wide1 = wide_ns >= 0;
-            if (wide1)
-                for (int k = tid; k < ncand; k += RS_T)
-                    if (W.cand_done[k]) V.label[W.cand_si[k]] = W.cand_sj[k];              // (sj = si - 1)
+            // ---- connected components of what is left by label propagation (label = lowest slot id of the cluster) ---------------
             for (;;) {
                 int changed = 0;
                 for (int k = tid; k < ncand; k += RS_T) {
-                    if (wide1 && W.cand_done[k]) continue;
+                    if (wide && W.cand_done[k]) continue;
                     const int sa = W.cand_si[k], sb = W.cand_sj[k];
                     if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
                     const int la = V.label[sa], lb = V.label[sb];
@@ -185,10 +185,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 if (!__syncthreads_or(changed)) break;
             }
         } else {
-            // ---- later rounds: the clusters of the previous round merge along the NEW edges only — a union over label
-            // values (parent map in V.size, roots = minimum label) and one relabelling pass, instead of propagating
-            // over every candidate again ----------------------------------------------------------------------------------------
-            for (int k = edges_new + tid; k < nedges; k += RS_T) {
+            // ---- later rounds: the clusters merge along the NEW edges only — a union over label values (parent map in
+            // V.size, roots = minimum label) and one relabelling pass, instead of propagating over every candidate again ----
+            for (int k = edges_merged + tid; k < nedges; k += RS_T) {
                 const int sa = W.edge_a[k], sb = W.edge_b[k];
                 if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
                 rs_union(V.size, V.label[sa], V.label[sb]);
@@ -199,21 +198,22 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             for (int s = tid; s < ns; s += RS_T) V.size[s] = 0;
             __syncthreads();
         }
-        ns_lab = ns;
         // ---- cluster sizes, accumulated on the label slot ------------------------------------------------------------------
         for (int s = tid; s < ns; s += RS_T) atomicAdd(&V.size[V.label[s]], 1);
         // clusters touched by the merge edges of the previous validation are re-emulated; everything else keeps its
         // results, events and history (tagged with the round they were produced in)
-        for (int k = edges_new + tid; k < nedges; k += RS_T) {
-            const int sa = W.edge_a[k], sb = W.edge_b[k];
-            if (sa >= 0 && sa < ns) vdirty[V.label[sa]] = 1;
-            if (sb >= 0 && sb < ns) vdirty[V.label[sb]] = 1;
-        }
+        if (!first)
+            for (int k = edges_merged + tid; k < nedges; k += RS_T) {
+                const int sa = W.edge_a[k], sb = W.edge_b[k];
+                if (sa >= 0 && sa < ns) vdirty[V.label[sa]] = 1;
+                if (sb >= 0 && sb < ns) vdirty[V.label[sb]] = 1;
+            }
+        if (!first) edges_merged = nedges;
+        ns_lab = ns;
         __syncthreads();
         for (int s = tid; s < ns; s += RS_T)
-            if (vdirty[V.label[s]] && !(rounds == 1 && s < wide_ns)) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; W.sl_hits[s] = 0; }
+            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; atomicAnd(&W.sl_hits[s], 0); }
         __syncthreads();
-        RS_STAMP(1);
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
         unsigned long long *keys = lds_keys;
         for (int s = tid; s < ns; s += RS_T) {
@@ -290,10 +290,10 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             // ---- two-particle clusters straight from the candidate list, both particles in registers ------------------------
             const int t0 = split ? tid - 64 : tid, tstride = split ? RS_T - 64 : RS_T;
             for (int k = t0; k < ncand; k += tstride) {
+                if (first && wide && W.cand_done[k]) continue;                     // emulated (and valid) by the wide kernel
                 const int si = W.cand_si[k], sj = W.cand_sj[k];
                 if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
                 if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
-                if (rounds == 1 && wide_ns >= 0 && W.cand_done[k]) continue;       // emulated by the wide pair kernel
                 rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
             }
         }
@@ -355,20 +355,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         __syncthreads();
         RS_STAMP(3);
         const int nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        if (!mono && MODE == 0) {
-            // ---- hand over to the wide validation kernel: labels to global memory, history into the overlay -------------
-            if (V.label != W.sl_label)
-                for (int s = tid; s < ns; s += RS_T) W.sl_label[s] = V.label[s];
-            for (int h = (sh.hist_begin > wide_nh ? sh.hist_begin : wide_nh) + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
-            __syncthreads();
-            if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.nslots0 = ns; *ctl = sh; }
-            RS_STAMP(4);
-            if (A.dbg && tid == 0) { A.dbg[8] += 1; A.dbg[9] += ncand; A.dbg[10] += sh.ncomplex; A.dbg[11] += 1; }
-            return;
-        }
-        // ---- validate: every new position against everything outside its cluster ------------------------------------------------
+        // ---- validate: every new position of this round against everything outside its cluster -------------------------------
         if (!A.allpairs) {
-            for (int h = (sh.hist_begin > wide_nh ? sh.hist_begin : wide_nh) + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
+            for (int h = sh.hist_begin + tid; h < nh; h += RS_T) W.ov_next[h] = atomicExch(&W.ov_head[rs_hist_cell(A, G, h)], h);
             __syncthreads();
             if (A.dbg && tid == 0) { const long long n__ = wall_clock64(); A.dbg[14] += n__ - t_last; }
             for (int h = sh.hist_begin + tid; h < nh; h += RS_T) rs_probe(A, G, &sh, V.label, ns, V.cap, h, cr2i);
@@ -379,6 +368,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const int h = hb + (int)(w / A.n);
                 const int idx = (int)(w % A.n);
                 const double4 hr = W.hist[h];
+                if (rs_hist_gen(hr) == 0) continue;
                 const int sme = rs_hist_slot(hr);
                 if (idx == V.p[sme]) continue;
                 const double ex = A.S.x[idx] - hr.x, ey = A.S.y[idx] - hr.y, ez = A.S.z[idx] - hr.z;
@@ -393,6 +383,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const int h = hb + (int)(w / nh), h2 = (int)(w % nh);
                 if (h2 >= h) continue;
                 const double4 ha = W.hist[h], hb2 = W.hist[h2];
+                if (rs_hist_gen(ha) == 0) continue;
                 const int s1 = rs_hist_slot(ha), s2 = rs_hist_slot(hb2);
                 if (rs_hist_gen(hb2) != W.sl_gen[s2]) continue;
                 if (V.label[s1] == V.label[s2]) continue;
@@ -402,24 +393,25 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         __syncthreads();
         RS_STAMP(4);
-        if (!sh.dirty || sh.ovf || rounds >= RS_MAX_ROUNDS) break;
+        // (the wide kernel's merge edges count as findings of the first round)
+        if (!(sh.dirty || (first && wide_dirty)) || sh.ovf || rounds >= RS_MAX_ROUNDS) break;
         __syncthreads();
     }
+    if (resolved) rounds = 1;
 
     const bool ok = !sh.ovf && !(sh.dirty && rounds >= RS_MAX_ROUNDS);
-    if (MODE == 1) {
+    if (!mono) {
         // the wide commit kernel finishes the sweep
         __syncthreads();
-        if (tid == 0) { sh.rounds = rounds; sh.edges_done = edges_done; sh.ok = ok; sh.dirty = 0; *ctl = sh; }
-        if (A.dbg && tid == 0) { A.dbg[8] += rounds - 1; A.dbg[12] += 1; }
+        if (tid == 0) { sh.rounds = rounds; sh.ok = ok; sh.dirty = 0; *ctl = sh; }
+        if (A.dbg && tid == 0) { A.dbg[8] += rounds; A.dbg[9] += ncand; A.dbg[10] += sh.ncomplex; A.dbg[11] += 1; }
         return;
     }
-    // ---- commit (monolithic path) ---------------------------------------------------------------------------------------
+    // ---- commit (small sweeps, no-grid mode) ----------------------------------------------------------------------------
     const int ns = sh.nslots < V.cap ? sh.nslots : V.cap;
-    if (!A.allpairs) {
-        const int nh_all = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-        for (int h = tid; h < nh_all; h += RS_T) W.ov_head[rs_hist_cell(A, G, h)] = -1;
-    }
+    const int nh_all = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+    if (!A.allpairs)
+        for (int h = tid; h < nh_all; h += RS_T) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;
     const bool defer = ok && A.defer_commit;        // the next streaming pass reads the slot arrays through slot_of[]
     for (int s = tid; s < ns && !defer; s += RS_T) {
         const int p = V.p[s];
@@ -431,12 +423,13 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         W.slot_of[p] = -1;
     }
-    if (tid == 0) sh.nhits = 0;
+    if (tid == 0) { sh.nhits = 0; sh.nfp = 0; }
     __syncthreads();
     if (ok) {
-        const int nev = sh.nev < W.max_events ? sh.nev : W.max_events;
-        for (int e = tid; e < nev; e += RS_T) {
-            if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;            // event of an emulation that was redone
+        for (int e = tid; e < nh_all; e += RS_T) {
+            const int g = W.ev_gen[e];
+            if (g == 0) continue;                                           // no completed path at this entry
+            if (g != W.sl_gen[W.ev_slot[e]]) continue;                      // event of an emulation that was redone
             const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];
             if (owner < A.lo || owner >= A.hi) continue;
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
@@ -445,7 +438,8 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         for (int s2 = tid; s2 < ns; s2 += RS_T) {
             // the counts were updated by atomics (performed in L2): read them there too, not from this CU's L1
             const int hs = __hip_atomic_load(&W.sl_hits[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (hs) atomicAdd(&sh.nhits, hs);
+            if (hs & 0xffff) atomicAdd(&sh.nhits, hs & 0xffff);
+            if (hs >> 16) atomicAdd(&sh.nfp, hs >> 16);
         }
     }
     __syncthreads();
@@ -469,61 +463,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     }
 }
 
-// ---- isolated pairs, wide -----------------------------------------------------------------------------------------------------
-// Everything in k_resolve costs time in proportion to the number of candidates (~38 ns each on its single CU).  Nine
-// candidates in ten are isolated pairs — both particles appear in no other candidate (degree one, counted by the detect
-// kernel) — and need none of its machinery: no claim race, no labels, no ordering against other pairs.  This kernel
-// gives them their slots (two per pair from one counter, allocated per wave) and emulates them exactly like the
-// workgroup would (rs_emulate_pair); the workgroup then starts from the counters left in W.wctl and handles only the
-// entangled remainder.  Validation treats both kinds alike (the pair's history entries are probed by k_validate).
-template <int GEOM>
-__global__ __launch_bounds__(256) void k_pairs_wide(rs_args A)
-{
-    const amc_resolve_ws &W = A.W;
-    rs_shared *wc = (rs_shared *)W.wctl;
-    int ncand = (int)A.O.cnt->cand_count;
-    if (ncand > W.max_cand) ncand = W.max_cand;
-    if (blockIdx.x == 0 && threadIdx.x == 0) wc->active = 1;
-    const unsigned int one = (A.sweep_epoch << 2) | 1u;
-    const int lane = threadIdx.x & 63, stride = gridDim.x * blockDim.x;
-    for (int k0 = blockIdx.x * blockDim.x + (threadIdx.x - lane); k0 < ncand; k0 += stride) {     // wave-uniform trip count
-        const int k = k0 + lane;
-        const bool valid = k < ncand;
-        int pi = 0, pj = 0;
-        bool iso = false;
-        if (valid) {
-            pi = W.cand_i[k]; pj = W.cand_j[k];
-            iso = W.deg[pi] == one && W.deg[pj] == one;
-        }
-        const int base = rs_count_add(&wc->nslots, iso ? 2 : 0);
-        if (iso && base + 1 >= W.max_slots) { wc->ovf = 1; iso = false; }
-        if (valid) W.cand_done[k] = iso ? 1 : 0;
-        if (!iso) continue;
-        const int sj = base, si = base + 1;
-        W.slot_of[pj] = sj; W.slot_of[pi] = si;
-        W.sl_p[sj] = pj; W.sl_p[si] = pi;
-        W.cand_sj[k] = sj; W.cand_si[k] = si;
-        W.sl_moved[sj] = 0; W.sl_moved[si] = 0;
-        W.sl_gen[sj] = 1; W.sl_gen[si] = 1;
-        atomicAnd(&W.sl_hits[sj], 0); atomicAnd(&W.sl_hits[si], 0);      // (atomics, like the increments that follow)
-        rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si);
-    }
-}
-
-// ---- wide kernels around the single-workgroup resolve (grid mode) ---------------------------------------------------------
-// validation of the first round: one thread per history entry, spread over the chip (the probes are scattered reads,
-// and one CU sustains only ~85 outstanding misses per microsecond)
-__global__ __launch_bounds__(64) void k_validate(rs_args A)
-{
-    rs_shared *ctl = (rs_shared *)A.W.ctl;
-    if (!ctl->active || ctl->ovf) return;
-    const int nh = ctl->nhist < A.W.max_hist ? ctl->nhist : A.W.max_hist;
-    const int ns = ctl->nslots0;        // slots that existed when the labels were written
-    const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
-    for (int h = ctl->hist_begin + blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
-        rs_probe(A, A.G, ctl, A.W.sl_label, ns, A.W.max_slots, h, cr2i);
-}
-
+// ---- wide commit (large sweeps) ---------------------------------------------------------------------------------------------
 // commit: scratch state -> particle arrays, completed paths -> histogram / records, counters; clears the overlay
 __global__ __launch_bounds__(256) void k_commit(rs_args A)
 {
@@ -550,12 +490,11 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     const bool ok = ctl->ok && !ctl->ovf;
     const bool defer = ok && A.defer_commit;
     const int ns = ctl->nslots < W.max_slots ? ctl->nslots : W.max_slots;
-    const int nev = ctl->nev < W.max_events ? ctl->nev : W.max_events;
     const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
-    int my_hits = 0;
+    int my_hits = 0, my_fp = 0;
     for (int s = gtid; s < ns; s += gstride) {
         const int p = W.sl_p[s];
-        if (ok && A.count_pp) my_hits += W.sl_hits[s];
+        if (ok && A.count_pp) { const int hs = W.sl_hits[s]; my_hits += hs & 0xffff; my_fp += hs >> 16; }
         if (defer) continue;
         if (ok && W.sl_moved[s]) {
             A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
@@ -566,11 +505,14 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         W.slot_of[p] = -1;
     }
     // one atomic per wave instead of one per slot on a single counter word
-    for (int o = 32; o > 0; o >>= 1) my_hits += __shfl_down(my_hits, o, 64);
+    for (int o = 32; o > 0; o >>= 1) { my_hits += __shfl_down(my_hits, o, 64); my_fp += __shfl_down(my_fp, o, 64); }
     if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(&A.O.banks[amc_bank_id()].n_pp, (unsigned long long)my_hits);
+    if ((threadIdx.x & 63) == 0 && my_fp) atomicAdd(&A.O.banks[amc_bank_id()].n_fp_errors, (unsigned long long)my_fp);
     if (ok)
-        for (int e = gtid; e < nev; e += gstride) {
-            if (W.ev_gen[e] != W.sl_gen[W.ev_slot[e]]) continue;          // event of an emulation that was redone since
+        for (int e = gtid; e < nh; e += gstride) {
+            const int g = W.ev_gen[e];
+            if (g == 0) continue;                                         // no completed path at this entry
+            if (g != W.sl_gen[W.ev_slot[e]]) continue;                    // event of an emulation that was redone since
             const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];      // the particle whose free path completed
             if (owner < A.lo || owner >= A.hi) continue;
             amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
@@ -582,11 +524,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         cnt->n_candidates += (unsigned long long)ctl->ncand;
         cnt->n_clusters += (unsigned long long)ctl->nclusters;
         cnt->n_rounds += (unsigned long long)ctl->rounds;
-        if (ok) {
-            if (A.count_pp) cnt->n_fp_errors += (unsigned long long)ctl->nfp;
-        } else {
-            cnt->flags |= 4ULL;
-        }
+        if (!ok) cnt->flags |= 4ULL;
         ctl->lazy_ns = defer ? ns : 0;
     }
 }
@@ -598,32 +536,23 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
         hipLaunchKernelGGL((k_resolve<GEOM, 2>), dim3(1), dim3(RS_T), 0, c->stream, A);
         return;
     }
-    // launch plan from the candidate count of the most recent sweep the host has seen (a word the kernel writes into
-    // host-mapped memory; no synchronisation, it may lag by a step): small sweeps need only this one kernel.  Either
-    // plan is correct for any count — a wrong guess only costs time.
-    if (!c->plan_split) {
-        rs_args B = A;
-        B.force_mono = 1;
-        hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, B);
-        return;
-    }
+    // grid mode: every small component wide first (emulation + its own validation), then the ordered workgroup for what
+    // is entangled beyond that.  Launch plan from the candidate count of the most recent sweep the host has seen (a word
+    // the kernel writes into host-mapped memory; no synchronisation, it may lag by a step): a small sweep is committed by
+    // the workgroup itself, a large one by the wide commit kernel.  Either plan is correct for any count.
     rs_args Aw = A;
     Aw.wide_plan = 1;
+    Aw.force_mono = c->plan_split ? 0 : 1;
     amc_prof_cancel(c);                 // (the caller's bracket is re-opened below, around the kernel it is named after)
     amc_prof_begin(c, AMC_K_PAIRS_WIDE);
-    hipLaunchKernelGGL((k_pairs_wide<GEOM>), dim3(64), dim3(256), 0, c->stream, Aw);
+    amc_launch_clusters_wide(c, Aw);
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_RESOLVE);
     hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, Aw);
-    amc_prof_end(c);
-    amc_prof_begin(c, AMC_K_VALIDATE);
-    hipLaunchKernelGGL(k_validate, dim3(128), dim3(64), 0, c->stream, A);
-    amc_prof_end(c);
-    amc_prof_begin(c, AMC_K_RESOLVE_MORE);
-    hipLaunchKernelGGL((k_resolve<GEOM, 1>), dim3(1), dim3(RS_T), 0, c->stream, A);
+    if (!c->plan_split) return;
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, Aw);
 }
 
 static rs_args rs_make_args(amc_ctx *c)

@@ -28,9 +28,12 @@ struct rs_args {
     long long lo, hi;         // owned particle range: completed paths are emitted by the owner of the particle
     double inv_dx, inv_dy, inv_dz;   // 1/dx.. for floor() GUESSES only (membership is decided by the exact comparisons)
     long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
-    unsigned int sweep_epoch; // tag of W.deg entries that belong to this sweep (0: degrees were not collected)
-    int wide_plan;            // k_pairs_wide ran before this kernel: start from the counters it left in W.wctl
+    unsigned int sweep_epoch; // tag of the W.adj_head entries that belong to this sweep
+    int wide_plan;            // k_clusters_wide ran before this kernel: start from the counters it left in W.wctl
 };
+
+struct amc_ctx;
+hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A);      // amc_clusters.hip
 
 // counters of one sweep; lives in LDS while a resolve kernel runs and in W.ctl (global) between the kernels
 struct rs_shared {
@@ -100,47 +103,92 @@ AMC_DEV int rs_count_add(int *counter, int n)
     return __shfl(base, leader, 64) + before;
 }
 
+// What the wide cluster kernel (amc_clusters.hip) hands to rs_hit: its history pairs are reserved before the emulation
+// starts (one counter increment per wave instead of one per hit) and every new position becomes a work item of the
+// publish-and-probe phase that follows the emulation.  nullptr inside the ordered workgroup.
+struct cw_item {
+    double x, y, z;
+    int h, own, p, pad;       // history entry, owner lane (its member list / slot range), particle
+};
+struct rs_wide {
+    int *pre_next;            // next reserved history pair of this lane / cluster
+    int pre_end;
+    cw_item *items;           // work items of the wave (LDS)
+    int *nitems;
+    int cap;
+    int own;
+    int *it0;                 // where the owner's first work item went (-1: none yet)
+    int *unval;               // set when a hit got entries the wave cannot publish: the ordered workgroup redoes the cluster
+};
+
+AMC_DEV void rs_store_hist(const amc_resolve_ws &W, int h, const double4 &r, bool coherent)
+{
+    if (coherent) {
+        // read by other workgroups of the same launch: write-through stores (agent scope), one per 8 bytes
+        double *d = (double *)&W.hist[h];
+        __hip_atomic_store(d + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 1, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 2, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(d + 3, r.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&W.ov_next[h], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        W.hist[h] = r;
+    }
+}
+
 // one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
 // Returns true if the particles moved.
 AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
-                    int si, int phase, long long cell)
+                    int si, int phase, long long cell, rs_wide *wd = nullptr)
 {
     const amc_resolve_ws &W = A.W;
-    auto emit = [&](int which, double tot, double px, double py, double pz) {
-        const int e = rs_count_add(&sh->nev, 1);
-        if (e < W.max_events) {
-            W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
-            W.ev_gen[e] = sh->cur_round; W.ev_slot[e] = si;
-            W.ev_val[4 * e + 0] = tot; W.ev_val[4 * e + 1] = px; W.ev_val[4 * e + 2] = py; W.ev_val[4 * e + 3] = pz;
-        } else {
-            sh->ovf = 1;
-        }
-    };
-    long long tq__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
-    const int fail__ = amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit);
-    if (A.dbg && threadIdx.x == 0) { if (p1.x == 1.2345e300) A.dbg[15] = 3; A.dbg[12] += wall_clock64() - tq__; }
-    if (fail__) {
-        atomicAdd(&sh->nfp, 1);     // the reference would raise FloatingPointError here (Pore:11,185)
-        return false;
-    }
-    atomicAdd(&W.sl_hits[si], 1);   // (no value needed back: the thread does not wait for the memory round trip)
-    const int h = rs_count_add(&sh->nhist, 2);
-    if (h + 1 < W.max_hist) {
-        W.hist[h] = rs_hist_make(p1.x, p1.y, p1.z, sj, sh->cur_round);
-        W.hist[h + 1] = rs_hist_make(p2.x, p2.y, p2.z, si, sh->cur_round);
-        if (!A.allpairs && !__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void *)sh)) {
-            // wide pair kernel (its counters live in global memory): the new positions go into the overlay lists right
-            // here, from thousands of waves, instead of one by one from the ordered workgroup's single CU later
-            int cx, cy, cz;
-            amc_grid_coords(A.G, p1.x, p1.y, p1.z, cx, cy, cz);
-            W.ov_next[h] = atomicExch(&W.ov_head[amc_grid_cell(A.G, cx, cy, cz, nullptr)], h);
-            amc_grid_coords(A.G, p2.x, p2.y, p2.z, cx, cy, cz);
-            W.ov_next[h + 1] = atomicExch(&W.ov_head[amc_grid_cell(A.G, cx, cy, cz, nullptr)], h + 1);
-        }
+    // the hit's pair of history entries (h: particle j, h + 1: particle i); its events use the same two indices
+    int h;
+    if (wd && *wd->pre_next + 2 <= wd->pre_end) {
+        h = *wd->pre_next;
+        *wd->pre_next = h + 2;
     } else {
-        sh->ovf = 1;
+        h = rs_count_add(&sh->nhist, 2);
+        if (wd) *wd->unval = 1;
     }
-    return true;
+    const bool room = h + 1 < W.max_hist;
+    if (!room) sh->ovf = 1;
+    const int gen = sh->cur_round;
+    if (room) { W.ev_gen[h] = 0; W.ev_gen[h + 1] = 0; }
+    auto emit = [&](int which, double tot, double px, double py, double pz) {
+        if (!room) return;
+        const int e = h + which;
+        W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
+        W.ev_slot[e] = si;
+        W.ev_val[4 * e + 0] = tot; W.ev_val[4 * e + 1] = px; W.ev_val[4 * e + 2] = py; W.ev_val[4 * e + 3] = pz;
+        W.ev_gen[e] = gen;
+    };
+    const int fail = amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit);
+    // counted on the slot — collisions in the low half, failed contact solves (the reference would raise
+    // FloatingPointError there, Pore:11,185) in the high half — so that a cluster that is emulated again starts from zero
+    // (no value needed back: the thread does not wait for the memory round trip)
+    atomicAdd(&W.sl_hits[si], fail ? 0x10000 : 1);
+    if (room) {
+        // (a failed hit moved nothing: its pair of entries stays empty — round 0 never matches a slot's round)
+        rs_store_hist(W, h, rs_hist_make(p1.x, p1.y, p1.z, sj, fail ? 0 : gen), wd != nullptr);
+        rs_store_hist(W, h + 1, rs_hist_make(p2.x, p2.y, p2.z, si, fail ? 0 : gen), wd != nullptr);
+        if (wd && !*wd->unval) {
+            // the wave publishes and probes the two new positions after the emulation (amc_clusters.hip); the empty
+            // pair of a failed hit keeps its place in the list (pad = 1: neither published nor probed)
+            const int it = atomicAdd(wd->nitems, 2);
+            if (it + 2 <= wd->cap) {
+                if (*wd->it0 < 0) *wd->it0 = it;             // the owner's items are contiguous, in the order of its reserved entries
+                cw_item a, b;
+                a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd->own; a.p = pj; a.pad = fail;
+                b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd->own; b.p = pi; b.pad = fail;
+                wd->items[it] = a;
+                wd->items[it + 1] = b;
+            } else {
+                *wd->unval = 1;
+            }
+        }
+    }
+    return !fail;
 }
 
 AMC_DEV int rs_pore_cell(const amc_params &P, double x, double y, double z, int gx, int gy, int gz)
@@ -229,16 +277,14 @@ AMC_DEV amc_particle rs_load_cst(const amc_resolve_ws &W, int k, int which)
 }
 
 template <int GEOM>
-AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int pi, int sj, int si)
+AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int pi, int sj, int si, rs_wide *wd = nullptr)
 {
     const amc_params &P = A.P;
-    long long t0__ = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     amc_particle p1 = rs_load_cst(A.W, k, 0), p2 = rs_load_cst(A.W, k, 1);   // coalesced rows gathered by detect
-    if (A.dbg && threadIdx.x == 0) { if (p1.x + p2.x == 1.2345e300) A.dbg[15] = 1; const long long t1__ = wall_clock64(); A.dbg[13] += t1__ - t0__; t0__ = t1__; }
     bool moved = false;
     const double cr = P.collision_range;
     if (GEOM == AMC_GEOM_CELL) {
-        if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr)) moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, 0);
+        if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr)) moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, 0, wd);
     } else if (GEOM == AMC_GEOM_CUBE) {
         // Cube:231-238.  A coordinate lies in at most two overlapping layers, so the layers holding BOTH members are
         // enumerated directly (rs_next_common) instead of walking all nx*ny*nz cells — lanes of a wave would each
@@ -253,7 +299,7 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int
                 for (int lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
                      lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1))
                     if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr))
-                        moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, ((long long)lx * P.ny + ly) * P.nz + lz);
+                        moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, ((long long)lx * P.ny + ly) * P.nz + lz, wd);
     } else {
         // Pore:522-530.  Along one axis a coordinate belongs to at most two overlapping cells k (one of each parity);
         // they are found once per particle (rs_axis_k) and re-derived only after a hit moved the particles, instead of
@@ -274,7 +320,7 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int
                     if (c1 >= 0 && c1 == rs_pore_cell_k(P, k2, g)) { hit_g = g; hit_c = c1; break; }
                 }
             if (hit_g < 0) break;
-            if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16 + hit_g, hit_c)) {
+            if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16 + hit_g, hit_c, wd)) {
                 moved = true;
                 rs_pore_ks(A, p1, k1);
                 rs_pore_ks(A, p2, k2);
@@ -290,12 +336,13 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int
 }
 
 // ---- generic cluster (3+ members): literal emulation on the working set [b,e) ----------------------
-AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int wj, int wi, int phase, long long cell)
+AMC_DEV void rs_test_work(const rs_args &A, rs_shared *sh, const rs_work &K, int wj, int wi, int phase, long long cell,
+                          rs_wide *wd = nullptr)
 {
     if (!amc_overlap(K.x[wj], K.y[wj], K.z[wj], K.x[wi], K.y[wi], K.z[wi], A.P.collision_range)) return;
     amc_particle p1 = rs_load_work(K, wj), p2 = rs_load_work(K, wi);
     const int pj = K.pidx[wj], pi = K.pidx[wi];
-    if (rs_hit(A, sh, p1, p2, pj, pi, K.slot[wj], K.slot[wi], phase, cell)) {
+    if (rs_hit(A, sh, p1, p2, pj, pi, K.slot[wj], K.slot[wi], phase, cell, wd)) {
         rs_store_work(K, wj, p1);
         rs_store_work(K, wi, p2);
     }
@@ -317,12 +364,12 @@ AMC_DEV int rs_next_layer(const rs_work &K, int b, int e, const double *v, int n
     return best;
 }
 
-AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
+AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e, rs_wide *wd = nullptr)
 {
     const amc_params &P = A.P;
     if (P.geometry == AMC_GEOM_CELL) {
         for (int a = b + 1; a < e; a++)                                                     // Pore:168-169
-            for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
+            for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0, wd);
     } else if (P.geometry == AMC_GEOM_CUBE) {
         // Cube:231-238 for a cluster: only layers that hold at least two members can do anything, so the next such
         // layer is found from the member pairs (rs_next_common) instead of walking all nx*ny*nz cells.  K.tmp bit0/1/2 =
@@ -349,7 +396,7 @@ AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &
                     for (int a = b + 1; a < e; a++) {
                         if (K.tmp[a] != 7) continue;
                         for (int c = b; c < a; c++)
-                            if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
+                            if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell, wd);
                     }
                 }
             }
@@ -368,7 +415,7 @@ AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &
                 const int ca = K.tmp[a];
                 if (ca < 0) continue;
                 for (int c = b; c < a; c++)
-                    if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
+                    if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca, wd);
             }
         }
     }
@@ -486,7 +533,7 @@ AMC_DEV int rs_next_layer_coop(const rs_work &K, int b, int pa, int pc, const do
     return rs_wave_min_nonneg(l);
 }
 
-AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e)
+AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e, rs_wide *wd = nullptr)
 {
     const amc_params &P = A.P;
     const int lane = threadIdx.x & 63, m = e - b;
@@ -496,7 +543,7 @@ AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, 
     if (P.geometry == AMC_GEOM_CELL) {
         if (lane == 0)
             for (int a = b + 1; a < e; a++)                                                 // Pore:168-169
-                for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0);
+                for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0, wd);
         rs_wave_sync();
     } else if (P.geometry == AMC_GEOM_CUBE) {
         // Cube:231-238, structure as in rs_emulate_generic (stale in_x / in_y / in_z masks in K.tmp bit 0/1/2)
@@ -526,7 +573,7 @@ AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, 
                         for (int a = b + 1; a < e; a++) {
                             if (K.tmp[a] != 7) continue;
                             for (int c = b; c < a; c++)
-                                if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell);
+                                if (K.tmp[c] == 7) rs_test_work(A, sh, K, c, a, 16, cell, wd);
                         }
                     }
                     rs_wave_sync();
@@ -549,7 +596,7 @@ AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, 
                     const int ca = K.tmp[a];
                     if (ca < 0) continue;
                     for (int c = b; c < a; c++)
-                        if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca);
+                        if (K.tmp[c] == ca) rs_test_work(A, sh, K, c, a, 16 + g, ca, wd);
                 }
             rs_wave_sync();
         }
@@ -562,6 +609,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
 {
     const amc_resolve_ws &W = A.W;
     const double4 me = W.hist[h];
+    if (rs_hist_gen(me) == 0) return;               // the pair of a hit that failed (no new position)
     const int sme = rs_hist_slot(me);
     const int pme = W.sl_p[sme];
     const int lme = label[sme];

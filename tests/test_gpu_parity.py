@@ -783,9 +783,9 @@ def test_tolerated_fp_events_match_oracle(Engine, O):
 # ---------------------------------------------------------------------------------------------- large-sweep launch plan
 @pytest.mark.parametrize("kind,n", [("cube", 400_000), ("pore", 1_000_000)])
 def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
-    """Sweeps with more than 430 candidates take the large plan: isolated pairs in k_pairs_wide, the entangled rest in
-    the ordered workgroup, wide validation, continuation, wide commit.  State and counters equal the oracle's bit for
-    bit at every step, and the profile shows that the wide pair kernel really ran."""
+    """Every sweep emulates its small clusters in the wide kernel (k_clusters_wide, validation included) and leaves the
+    entangled rest to the ordered workgroup; sweeps with many candidates are committed by the wide commit kernel.  State
+    and counters equal the oracle's bit for bit at every step, and the profile shows that both wide kernels ran."""
     if kind == "cube":
         p, c = PR.cube_params_for_n(n)
         init = IC.cube_ic(p, c, seed=127)
@@ -810,7 +810,7 @@ def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
     kt = eng.kernel_times()
     eng.profile(False)
     assert ncand > 640
-    assert kt["pairs_wide"][1] >= 4 and kt["validate"][1] >= 4 and kt["commit"][1] >= 4, kt
+    assert kt["pairs_wide"][1] >= 6 and kt["commit"][1] >= 4, kt
     eng.close()
 
 
