@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <new>
+#include <type_traits>
 
 #include "amc_host.h"
 
@@ -159,16 +160,9 @@ void amc_destroy(amc_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
-                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.cand_i, c->W.cand_j, c->W.slot_of, c->W.sl_p, c->W.sl_label,
-                    c->W.sl_tmp, c->W.sl_key, c->W.order, c->W.sl_x, c->W.sl_y, c->W.sl_z, c->W.sl_vx, c->W.sl_vy,
-                    c->W.sl_vz, c->W.sl_d, c->W.sl_dx, c->W.sl_dy, c->W.sl_dz, c->W.sl_flag, c->W.sl_moved, c->W.edge_a,
-                    c->W.edge_b, c->W.hist, c->W.ov_head, c->W.ov_next,
-                    c->W.ev_phase, c->W.ev_i, c->W.ev_j, c->W.ev_which, c->W.ev_cell, c->W.ev_val, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->d_banks, c->W.cw_d[0], c->W.cw_d[1], c->W.cw_d[2],
-                    c->W.cw_d[3], c->W.cw_d[4], c->W.cw_d[5], c->W.cw_d[6], c->W.cw_d[7], c->W.cw_d[8], c->W.cw_d[9],
-                    c->W.cw_tmp, c->W.cw_pidx, c->W.cw_slot, c->W.cw_flag, c->W.cw_moved, c->W.cand_si, c->W.cand_sj, c->d_dbg, c->W.cst, c->W.ctl, c->T.idx, c->T.count, c->T.t, c->T.contact,
-                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok, c->W.sl_dirty, c->W.sl_gen, c->W.sl_hits,
-                    c->W.ev_gen, c->W.ev_slot, c->W.wctl, c->W.adj_head, c->W.cand4, c->W.cand_done};
+                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.ov_head, c->w_slab, c->d_rec, c->d_hist,
+                    c->d_edges, c->d_cnt, c->d_banks, c->d_dbg, c->T.idx, c->T.count, c->T.t, c->T.contact,
+                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -217,7 +211,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
-    c->d_dbg = nullptr;
+    c->d_dbg = nullptr; c->w_slab = nullptr;
     c->mg_count_pp = true;
     c->lazy_pending = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
@@ -271,38 +265,48 @@ int amc_create(amc_ctx **out, const amc_params *p)
         W.max_slots = (int)std::min<long long>(2 * mc, std::max<long long>(c->n, 2));
         W.max_edges = 4 * W.max_slots + 1024;
         W.max_hist = 8 * W.max_slots + 1024;
-        CK(dalloc(&W.cand_i, (size_t)W.max_cand)); CK(dalloc(&W.cand_j, (size_t)W.max_cand));
-        CK(dalloc(&W.cand_si, (size_t)W.max_cand)); CK(dalloc(&W.cand_sj, (size_t)W.max_cand));
-        CK(dalloc(&W.cst, (size_t)22 * W.max_cand));
-        CK(dalloc(&W.ctl, 64));
-        CK(hipMemsetAsync(W.ctl, 0, sizeof(int) * 64, c->stream));
-        CK(dalloc(&W.wctl, 64));
-        CK(hipMemsetAsync(W.wctl, 0, sizeof(int) * 64, c->stream));
+        // ONE allocation for the whole sweep work space: the resolve kernels are chains of dependent, scattered accesses to
+        // some sixty small arrays — carved from one slab they share a handful of translation entries instead of one each
+        {
+            const size_t ms = (size_t)W.max_slots;
+            auto carve = [&](char *base) -> size_t {
+                size_t off = 0;
+                auto take = [&](auto **pp, size_t count) {
+                    using T = std::remove_pointer_t<std::remove_pointer_t<decltype(pp)>>;
+                    off = (off + 255) & ~(size_t)255;
+                    *pp = base ? (T *)(base + off) : nullptr;
+                    off += sizeof(T) * std::max<size_t>(count, 1);
+                };
+                take(&W.ctl, 64); take(&W.wctl, 64);
+                take(&W.cand_i, (size_t)W.max_cand); take(&W.cand_j, (size_t)W.max_cand);
+                take(&W.cand_si, (size_t)W.max_cand); take(&W.cand_sj, (size_t)W.max_cand);
+                take(&W.cand4, (size_t)W.max_cand); take(&W.cand_done, (size_t)W.max_cand);
+                take(&W.cst, (size_t)22 * W.max_cand);
+                take(&W.sl_p, ms); take(&W.sl_label, ms); take(&W.sl_tmp, ms); take(&W.order, ms);
+                take(&W.sl_key, (size_t)next_pow2(W.max_slots));
+                double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
+                for (auto pp : sl) take(pp, ms);
+                take(&W.sl_flag, ms); take(&W.sl_moved, ms); take(&W.sl_dirty, ms);
+                take(&W.sl_gen, ms); take(&W.sl_hits, ms);
+                for (int k = 0; k < 10; k++) take(&W.cw_d[k], ms);
+                take(&W.cw_tmp, ms); take(&W.cw_pidx, ms); take(&W.cw_slot, ms); take(&W.cw_flag, ms); take(&W.cw_moved, ms);
+                take(&W.edge_a, (size_t)W.max_edges); take(&W.edge_b, (size_t)W.max_edges);
+                take(&W.hist, (size_t)W.max_hist); take(&W.ov_next, (size_t)W.max_hist);
+                take(&W.ev_phase, (size_t)W.max_hist); take(&W.ev_i, (size_t)W.max_hist);
+                take(&W.ev_j, (size_t)W.max_hist); take(&W.ev_which, (size_t)W.max_hist);
+                take(&W.ev_cell, (size_t)W.max_hist); take(&W.ev_val, (size_t)4 * W.max_hist);
+                take(&W.ev_gen, (size_t)W.max_hist); take(&W.ev_slot, (size_t)W.max_hist);
+                take(&W.adj_head, n); take(&W.slot_of, n);
+                return (off + 255) & ~(size_t)255;
+            };
+            const size_t total = carve(nullptr);
+            CK(hipMalloc((void **)&c->w_slab, total));
+            CK(hipMemsetAsync(c->w_slab, 0, total, c->stream));
+            carve(c->w_slab);
+        }
         { amc_resolve_ctl z; memset(&z, 0, sizeof z); z.cur_round = 1; CK(hipMemcpyAsync(W.wctl, &z, sizeof z, hipMemcpyHostToDevice, c->stream)); CK(hipStreamSynchronize(c->stream)); }
-        CK(dalloc(&W.adj_head, n));
-        CK(hipMemsetAsync(W.adj_head, 0, sizeof(unsigned long long) * std::max<size_t>(n, 1), c->stream));
-        CK(dalloc(&W.cand4, (size_t)W.max_cand));
-        CK(dalloc(&W.cand_done, (size_t)W.max_cand));
-        CK(hipMemsetAsync(W.cand_done, 0, (size_t)W.max_cand, c->stream));
         c->sweep_epoch = 0;
-        CK(dalloc(&W.slot_of, n));
         CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));
-        const size_t ms = (size_t)W.max_slots;
-        CK(dalloc(&W.sl_p, ms)); CK(dalloc(&W.sl_label, ms)); CK(dalloc(&W.sl_tmp, ms)); CK(dalloc(&W.order, ms));
-        CK(dalloc(&W.sl_key, (size_t)next_pow2(W.max_slots)));
-        double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
-        for (auto pp : sl) CK(dalloc(pp, ms));
-        CK(dalloc(&W.sl_flag, ms)); CK(dalloc(&W.sl_moved, ms)); CK(dalloc(&W.sl_dirty, ms));
-        CK(dalloc(&W.sl_gen, ms)); CK(dalloc(&W.sl_hits, ms));
-        for (int k = 0; k < 10; k++) CK(dalloc(&W.cw_d[k], ms));
-        CK(dalloc(&W.cw_tmp, ms)); CK(dalloc(&W.cw_pidx, ms)); CK(dalloc(&W.cw_slot, ms)); CK(dalloc(&W.cw_flag, ms)); CK(dalloc(&W.cw_moved, ms));
-        CK(dalloc(&W.edge_a, (size_t)W.max_edges)); CK(dalloc(&W.edge_b, (size_t)W.max_edges));
-        CK(dalloc(&W.hist, (size_t)W.max_hist)); CK(dalloc(&W.ov_next, (size_t)W.max_hist));
-        CK(dalloc(&W.ev_phase, (size_t)W.max_hist)); CK(dalloc(&W.ev_i, (size_t)W.max_hist));
-        CK(dalloc(&W.ev_j, (size_t)W.max_hist)); CK(dalloc(&W.ev_which, (size_t)W.max_hist));
-        CK(dalloc(&W.ev_cell, (size_t)W.max_hist)); CK(dalloc(&W.ev_val, (size_t)4 * W.max_hist));
-        CK(dalloc(&W.ev_gen, (size_t)W.max_hist)); CK(dalloc(&W.ev_slot, (size_t)W.max_hist));
-        CK(hipMemsetAsync(W.ev_gen, 0, sizeof(int) * (size_t)W.max_hist, c->stream));
         // outputs
         long long mp = p->max_paths > 0 ? p->max_paths : (p->max_paths < 0 ? 0 : (1LL << 20));   // < 0: histograms only
         if (mp > 0x7fffffff) mp = 0x7fffffff;
@@ -338,8 +342,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         c->h_pin_bytes = (size_t)4 << 20;
         if (hipHostMalloc((void **)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; c->h_pin_bytes = 0; }
         if (getenv("AMC_DEBUG_RESOLVE")) {
-            CK(dalloc(&c->d_dbg, 16));
-            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 16, c->stream));
+            CK(dalloc(&c->d_dbg, 32));
+            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 32, c->stream));
         }
         CK(hipStreamSynchronize(c->stream));
     }
@@ -739,12 +743,15 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
     hipSetDevice(c->device);
     amc_prof_collect(c);
     if (c->d_dbg) {
-        long long h[16];
+        long long h[32];
         hipMemcpy(h, c->d_dbg, sizeof h, hipMemcpyDeviceToHost);
         const double n = h[11] > 0 ? (double)h[11] : 1.0;
-        fprintf(stderr, "[amc resolve phases, us/launch] claim %.1f label %.1f [collect %.1f tid0-pair %.1f (load %.1f ks %.1f collide+emit %.1f)] clusters>=3: sort+load %.1f emulate %.1f | validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
-                h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[13] / n / 100.0, h[14] / n / 100.0, h[12] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
+        fprintf(stderr, "[amc k_resolve phases, us/launch] count-left %.1f claim %.1f | rounds: collect %.1f pairs %.1f clusters>=3: sort+load %.1f emulate %.1f | overlay %.1f validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
+                h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[14] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
                 h[8] / n, h[9] / n, h[10] / n, h[11]);
+        const double w = h[31] > 0 ? (double)h[31] : 1.0;
+        fprintf(stderr, "[amc k_clusters_wide phases, us per working wave] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f | waves %lld\n",
+                h[16] / w / 100.0, h[17] / w / 100.0, h[18] / w / 100.0, h[19] / w / 100.0, h[20] / w / 100.0, h[21] / w / 100.0, h[22] / w / 100.0, h[31]);
     }
     for (int k = 0; k < AMC_K_COUNT; k++) {
         if (total_ms) total_ms[k] = c->k_ms[k];

@@ -28,6 +28,8 @@
 //
 // Bound: latency (a chain of ~8 dependent memory round trips per candidate), which is why the candidates are spread as
 // thinly as the launch allows: CW_BLOCKS one-wave workgroups, ceil(ncand / CW_BLOCKS) candidates per wave.
+#include <stdlib.h>
+
 #include "amc_resolve_dev.h"
 
 #define CW_MAXM 16          // particles of a component handled here
@@ -61,25 +63,14 @@ AMC_DEV void cw_reserve2(int *ca, int na, int *cb, int nb, int &base_a, int &bas
     base_b = __shfl(bb, 0, 64) + ib - nb;
 }
 
-// a particle outside every cluster gets a slot (it joins a cluster in the ordered workgroup's next round)
-AMC_DEV void cw_claim(const amc_resolve_ws &W, rs_shared *wc, int idx)
-{
-    const int old = atomicCAS(&W.slot_of[idx], -1, -2);
-    if (old != -1) return;
-    const int s = atomicAdd(&wc->nslots, 1);
-    if (s < W.max_slots) {
-        W.sl_p[s] = idx; W.sl_label[s] = s; W.sl_moved[s] = 0; W.sl_gen[s] = 0;
-        atomicAnd(&W.sl_hits[s], 0);
-        W.slot_of[idx] = s;
-    } else {
-        wc->ovf = 1;
-        W.slot_of[idx] = -1;
-    }
-}
+#define CW_ITERS 3          // emulations of one cluster in this kernel: the first + two after it pulled particles in
+#define CW_PULLS 4          // particles one cluster can pull in per validation
 
-AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label)
+AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label, int gen)
 {
-    W.slot_of[p] = s; W.sl_p[s] = p; W.sl_label[s] = label; W.sl_moved[s] = 0; W.sl_gen[s] = 1;
+    W.slot_of[p] = s; W.sl_p[s] = p; W.sl_label[s] = label; W.sl_moved[s] = 0;
+    // (write-through: a prober of another workgroup that meets one of this slot's history entries compares rounds)
+    __hip_atomic_store(&W.sl_gen[s], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     atomicAnd(&W.sl_hits[s], 0);        // (an atomic, like the increments that follow)
 }
 
@@ -95,9 +86,14 @@ AMC_DEV double4 cw_load_hist(const amc_resolve_ws &W, int h)
 }
 
 struct cw_lds {
-    int mem[64][CW_MAXM];       // per owner lane: the particles of its component (sorted ascending before use)
-    int cnd[64][CW_MAXC];       // and its candidates
-    int nm[64], nc[64], base[64], hb[64], he[64], it0[64];   // members, candidates, first slot, reserved entries [hb, he), first work item
+    int mem[64][CW_MAXM];       // per owner lane: the particles of its cluster (ascending when emulated)
+    int msl[64][CW_MAXM];       // and their slots
+    int cnd[64][CW_MAXC];       // its candidates
+    int pull[64][CW_PULLS], psl[64][CW_PULLS];     // particles (and their new slots) the last validation pulled in
+    int nm[64], nc[64], lab[64], npull[64];         // members, candidates, cluster label (= first slot), pulls
+    int hb[64][CW_ITERS], he[64][CW_ITERS], it0[64][CW_ITERS];   // per emulation: reserved entries [hb, he), first work item
+    int redo[64];               // the cluster must be emulated (again) by the wave
+    int gen[64];                // emulations done
     cw_item item[CW_ITEMS];
     int next[CW_ITEMS];         // overlay `next` of every published item (own entries are stepped over without a load)
     int nitems, hnext, unval;
@@ -106,11 +102,13 @@ struct cw_lds {
     uint8_t pool_flag[CW_MAXM], pool_moved[CW_MAXM];
 };
 
-// probe of one published position: everything outside its cluster within the (inflated) collision range is a merge edge
+// probe of one published position: everything outside its cluster within the (inflated) collision range either joins
+// the cluster (a particle that is in no candidate and that nobody else has taken: the owner emulates again with it) or
+// becomes a merge edge for the ordered workgroup
 AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, double cr2i)
 {
     const amc_resolve_ws &W = A.W;
-    const int own = me.own, nm = L.nm[own], base = L.base[own], hb = L.hb[own], he = L.he[own], it0 = L.it0[own];
+    const int own = me.own, nm = L.nm[own], lab = L.lab[own];
     const double x = me.x, y = me.y, z = me.z;
     int c_lo[4], c_hi[4], lh[8], ovh[8];
     const int ncell = amc_grid_box_ranges(A.G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
@@ -126,10 +124,16 @@ AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item 
             }
         }
     }
-    // entries of my own cluster are stepped over through the `next` values its pushes returned (LDS), without a load
+    // entries of my own cluster (of this and of earlier emulations) are stepped over through the `next` values their
+    // pushes returned (LDS), without a load
     auto skip_own = [&](int h2) {
-        while (h2 >= hb && h2 < he) h2 = L.next[it0 + (h2 - hb)];
-        return h2;
+        for (;;) {
+            int r = 0;
+            for (; r < CW_ITERS; r++)
+                if (h2 >= L.hb[own][r] && h2 < L.he[own][r]) break;
+            if (r == CW_ITERS) return h2;
+            h2 = L.next[L.it0[own][r] + (h2 - L.hb[own][r])];
+        }
     };
     auto member = [&](int idx) {
         for (int m = 0; m < nm; m++)
@@ -140,15 +144,35 @@ AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item 
         const double ax = r.x - x, ay = r.y - y, az = r.z - z;
         if (!(ax * ax + ay * ay + az * az < cr2i)) return;
         if (member(idx)) return;
-        if (cw_adj_head(W, A.sweep_epoch, idx) < 0) cw_claim(W, wc, idx);   // in no candidate: give it a slot now
+        if (cw_adj_head(W, A.sweep_epoch, idx) < 0) {
+            // in no candidate: pull it into this cluster, unless somebody else got it first
+            const int tag = -(lab + 2);
+            const int old = atomicCAS(&W.slot_of[idx], -1, tag);
+            if (old == tag) return;                             // another position of my cluster found it too
+            if (old == -1) {
+                const int s = atomicAdd(&wc->nslots, 1);
+                const int k = atomicAdd(&L.npull[own], 1);
+                if (s < W.max_slots && k < CW_PULLS) {
+                    L.pull[own][k] = idx; L.psl[own][k] = s;   // (slot_of keeps the tag until the owner initialises the slot)
+                    L.redo[own] = 1;
+                    return;
+                }
+                if (s >= W.max_slots) wc->ovf = 1;
+                else { W.sl_p[s] = idx; W.sl_label[s] = s; W.sl_moved[s] = 0; W.sl_gen[s] = 0; atomicAnd(&W.sl_hits[s], 0); }
+                W.slot_of[idx] = s < W.max_slots ? s : -1;      // too many at once: a plain merge edge instead
+            }
+        }
         rs_add_edge(W, wc, me.p, idx);
     };
     auto overlay_entry = [&](const double4 &o) {
-        const int s2 = rs_hist_slot(o);
-        if (s2 >= base && s2 < base + nm) return;
-        if (rs_hist_gen(o) == 0) return;
         const double ax = o.x - x, ay = o.y - y, az = o.z - z;
-        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, wc, me.p, -(s2 + 2));    // (the other end as a slot)
+        if (!(ax * ax + ay * ay + az * az < cr2i)) return;
+        const int s2 = rs_hist_slot(o);
+        for (int m = 0; m < nm; m++)
+            if (L.msl[own][m] == s2) return;
+        // position of an emulation that was redone since?  (its owner raised the slot's round before it published anew)
+        if (rs_hist_gen(o) != __hip_atomic_load(&W.sl_gen[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        rs_add_edge(W, wc, me.p, -(s2 + 2));                    // (the other end as a slot)
     };
     // first element of every list before any is examined (the probe is a chain of dependent round trips)
     double4 r0[8], o0[8];
@@ -205,6 +229,17 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
     K.d = L.pool_d[6]; K.dx = L.pool_d[7]; K.dy = L.pool_d[8]; K.dz = L.pool_d[9];
     K.tmp = L.pool_tmp; K.pidx = L.pool_pidx; K.slot = L.pool_slot; K.flag = L.pool_flag; K.moved = L.pool_moved;
 
+    long long t_last = (A.dbg && lane == 0) ? wall_clock64() : 0;
+#define CW_STAMP(slot)                                                                     \
+    do {                                                                                   \
+        if (timed__) {                                                                     \
+            const long long now__ = wall_clock64();                                        \
+            atomicAdd((unsigned long long *)&A.dbg[16 + slot], (unsigned long long)(now__ - t_last));   \
+            t_last = now__;                                                                \
+        }                                                                                  \
+    } while (0)
+    const bool timed__ = A.dbg && lane == 0 && blockIdx.x * per < ncand;     // waves with work in their first pass
+    if (timed__) atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
     for (int k0 = blockIdx.x * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
         const bool valid = lane < per && k < ncand;
@@ -218,6 +253,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
             head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
         }
         const bool iso = valid && head_i == k && c4.z < 0 && head_j == k && c4.w < 0;
+        CW_STAMP(0);
         bool owner = valid && !iso;
         int nm = 2, nc = 1;
         int *mem = L.mem[lane], *cnd = L.cnd[lane];
@@ -254,14 +290,19 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     mem[b + 1] = v;
                 }
         }
+        CW_STAMP(1);
         // ---- 2. slots and history pairs for everything this wave owns ---------------------------------------------------
         const int want_s = iso ? 2 : (owner ? nm : 0), want_h = iso ? 2 : (owner ? 2 * nc : 0);
         int sbase, hbase;
         cw_reserve2(&wc->nslots, want_s, &wc->nhist, want_h, sbase, hbase);
         bool take = iso || owner;
         if (take && (sbase + want_s > W.max_slots || hbase + want_h > W.max_hist)) { wc->ovf = 1; take = false; }
-        L.nm[lane] = nm; L.nc[lane] = nc; L.base[lane] = sbase; L.hb[lane] = hbase; L.he[lane] = hbase + (take ? want_h : 0);
-        L.it0[lane] = -1;
+        L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = sbase; L.npull[lane] = 0;
+        for (int m = 0; m < nm; m++) L.msl[lane][m] = sbase + m;
+        for (int r = 0; r < CW_ITERS; r++) { L.hb[lane][r] = 0; L.he[lane][r] = 0; L.it0[lane][r] = -1; }
+        L.hb[lane][0] = hbase; L.he[lane][0] = hbase + (take ? want_h : 0);
+        L.redo[lane] = (owner && take) ? 1 : 0;
+        L.gen[lane] = 0;
         if (take)
             for (int e = hbase; e < hbase + want_h; e++) W.ev_gen[e] = 0;       // "no event" until a hit stores one
         {
@@ -269,79 +310,136 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
             if (lane == 0 && ncl) atomicAdd(&wc->nclusters, ncl);
         }
         __syncthreads();
+        CW_STAMP(2);
         // ---- 3a. isolated pairs: both particles in registers ------------------------------------------------------------------
         if (iso && take) {
             const int pj = c4.y, pi = c4.x, sj = sbase, si = sbase + 1;
-            cw_init_slot(W, sj, pj, sj);
-            cw_init_slot(W, si, pi, sj);
+            cw_init_slot(W, sj, pj, sj, 1);
+            cw_init_slot(W, si, pi, sj, 1);
             W.cand_sj[k] = sj; W.cand_si[k] = si; W.cand_done[k] = 1;
             int pre_next = hbase, unval = 0;
             rs_wide wd;
             wd.pre_next = &pre_next; wd.pre_end = hbase + 2; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-            wd.own = lane; wd.it0 = &L.it0[lane]; wd.unval = &unval;
+            wd.own = lane; wd.gen = 1; wd.it0 = &L.it0[lane][0]; wd.unval = &unval;
             rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
+            L.gen[lane] = 1;
             if (unval) rs_add_edge(W, wc, pi, pi);          // (self edge: the ordered workgroup redoes this cluster)
         }
-        // ---- 3b. larger clusters, one after the other by the whole wave ----------------------------------------------------------
-        unsigned long long owners = __ballot(owner && take);
-        while (owners) {
-            const int src = __ffsll((long long)owners) - 1;
-            owners &= owners - 1;
-            const int m = L.nm[src], ncs = L.nc[src], base = L.base[src];
-            if (lane == 0) { L.hnext = L.hb[src]; L.unval = 0; }
-            if (lane < m) {
-                const int p = L.mem[src][lane];
-                const amc_particle q = rs_load_particle(A.S, p);
-                rs_store_work(K, lane, q);
-                K.moved[lane] = 0; K.pidx[lane] = p; K.slot[lane] = base + lane;
-                cw_init_slot(W, base + lane, p, base);
-            }
-            for (int e = lane; e < ncs; e += 64) {
-                const int c = L.cnd[src][e];
-                const int pi = W.cand_i[c], pj = W.cand_j[c];
-                int ai = 0, aj = 0;
-                for (int t = 0; t < m; t++) { if (L.mem[src][t] == pi) ai = t; if (L.mem[src][t] == pj) aj = t; }
-                W.cand_si[c] = base + ai; W.cand_sj[c] = base + aj; W.cand_done[c] = 1;
-            }
+        CW_STAMP(3);
+        int first_item = 0;
+        for (int iter = 0; iter < CW_ITERS; iter++) {
+            // ---- 3b. clusters to be emulated (again), one after the other by the whole wave -------------------------------------
             __syncthreads();
-            rs_wide wd;
-            wd.pre_next = &L.hnext; wd.pre_end = L.he[src]; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-            wd.own = src; wd.it0 = &L.it0[src]; wd.unval = &L.unval;
-            if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
-            else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
-            __syncthreads();
-            if (lane < m && K.moved[lane]) rs_store_slot(W, K.slot[lane], rs_load_work(K, lane));
-            if (lane == 0 && L.unval) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);
-            __syncthreads();
-        }
-        // ---- 4. publish every new position, then probe them ---------------------------------------------------------------------
-        __syncthreads();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the history records (write-through stores) have left
-        const int nit = L.nitems < CW_ITEMS ? L.nitems : CW_ITEMS;
-        for (int t0 = 0; t0 < nit; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < nit) L.next[t] = -1;
-            if (t < nit && !L.item[t].pad) {
-                const cw_item it = L.item[t];
-                int cx, cy, cz;
-                amc_grid_coords(A.G, it.x, it.y, it.z, cx, cy, cz);
-                const int cell = amc_grid_cell(A.G, cx, cy, cz, nullptr);
-                int expected = -1;                              // (the record was stored with next = -1)
-                for (;;) {
-                    const int old = atomicCAS(&W.ov_head[cell], expected, it.h);
-                    if (old == expected) break;
-                    expected = old;
-                    __hip_atomic_store(&W.ov_next[it.h], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long todo = __ballot(L.redo[lane] != 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int g = L.gen[src], ncs = L.nc[src], lab = L.lab[src];
+                if (lane == 0) {
+                    // particles the last validation pulled in become members; a new range of history pairs
+                    int m = L.nm[src];
+                    const int np = L.npull[src] < CW_PULLS ? L.npull[src] : CW_PULLS;
+                    L.unval = 0;
+                    for (int e = 0; e < np; e++) {
+                        const int v = L.pull[src][e], sv = L.psl[src][e];
+                        if (m == CW_MAXM) {             // no room: it keeps its slot (same label) and the ordered workgroup takes over
+                            cw_init_slot(W, sv, v, lab, 0);
+                            L.unval = 2;
+                            continue;
+                        }
+                        int b = m - 1;
+                        while (b >= 0 && L.mem[src][b] > v) { L.mem[src][b + 1] = L.mem[src][b]; L.msl[src][b + 1] = L.msl[src][b]; b--; }
+                        L.mem[src][b + 1] = v; L.msl[src][b + 1] = sv;
+                        m++;
+                    }
+                    L.nm[src] = m; L.npull[src] = 0;
+                    if (g > 0) {
+                        const int want = 2 * (ncs + m);
+                        const int hb = atomicAdd(&wc->nhist, want);
+                        if (hb + want > W.max_hist) { wc->ovf = 1; L.hb[src][g] = 0; L.he[src][g] = 0; }
+                        else {
+                            L.hb[src][g] = hb; L.he[src][g] = hb + want;
+                            for (int e = hb; e < hb + want; e++) W.ev_gen[e] = 0;
+                        }
+                    }
+                    L.hnext = L.hb[src][g];
                 }
-                L.next[t] = expected;
+                __syncthreads();
+                const int m = L.nm[src];
+                if (lane < m) {
+                    const int p = L.mem[src][lane], sl = L.msl[src][lane];
+                    const amc_particle q = rs_load_particle(A.S, p);
+                    rs_store_work(K, lane, q);
+                    K.moved[lane] = 0; K.pidx[lane] = p; K.slot[lane] = sl;
+                    cw_init_slot(W, sl, p, lab, g + 1);
+                }
+                if (g == 0)
+                    for (int e = lane; e < ncs; e += 64) {
+                        const int c = L.cnd[src][e];
+                        const int pi = W.cand_i[c], pj = W.cand_j[c];
+                        int ai = 0, aj = 0;
+                        for (int t = 0; t < m; t++) { if (L.mem[src][t] == pi) ai = t; if (L.mem[src][t] == pj) aj = t; }
+                        W.cand_si[c] = L.msl[src][ai]; W.cand_sj[c] = L.msl[src][aj]; W.cand_done[c] = 1;
+                    }
+                __syncthreads();
+                rs_wide wd;
+                wd.pre_next = &L.hnext; wd.pre_end = L.he[src][g]; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+                wd.own = src; wd.gen = g + 1; wd.it0 = &L.it0[src][g]; wd.unval = &L.unval;
+                if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
+                else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
+                __syncthreads();
+                if (lane < m && K.moved[lane]) rs_store_slot(W, K.slot[lane], rs_load_work(K, lane));
+                if (lane == 0) {
+                    if (L.unval) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);     // (self edge: the ordered workgroup redoes it)
+                    L.gen[src] = g + 1;
+                    L.redo[src] = 0;
+                }
+                __syncthreads();
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every push of this wave has returned
-        __syncthreads();
-        for (int t0 = 0; t0 < nit; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < nit && !L.item[t].pad) cw_probe(A, wc, L, L.item[t], cr2i);
+            CW_STAMP(4);
+            // ---- 4. publish every new position of this turn, then probe them ----------------------------------------------------
+            __syncthreads();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the history records (write-through stores) have left
+            const int nit = L.nitems < CW_ITEMS ? L.nitems : CW_ITEMS;
+            for (int t0 = first_item; t0 < nit; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < nit) L.next[t] = -1;
+                if (t < nit && !L.item[t].pad) {
+                    const cw_item it = L.item[t];
+                    int cx, cy, cz;
+                    amc_grid_coords(A.G, it.x, it.y, it.z, cx, cy, cz);
+                    const int cell = amc_grid_cell(A.G, cx, cy, cz, nullptr);
+                    int expected = -1;                              // (the record was stored with next = -1)
+                    for (;;) {
+                        const int old = atomicCAS(&W.ov_head[cell], expected, it.h);
+                        if (old == expected) break;
+                        expected = old;
+                        __hip_atomic_store(&W.ov_next[it.h], old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    L.next[t] = expected;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every push of this wave has returned
+            __syncthreads();
+            CW_STAMP(5);
+            for (int t0 = first_item; t0 < nit; t0 += 64) {
+                const int t = t0 + lane;
+                if (t < nit && !L.item[t].pad) cw_probe(A, wc, L, L.item[t], cr2i);
+            }
+            first_item = nit;
+            CW_STAMP(6);
+            // a cluster that pulled particles in is emulated again from the untouched pre-sweep state, unless it has had
+            // its turns: then the particles still get their slots and the ordered workgroup takes over
+            if (!__syncthreads_or(L.redo[lane])) break;
+            if (iter + 1 == CW_ITERS || L.nitems >= CW_ITEMS - 8) {
+                if (L.redo[lane]) {
+                    const int np = L.npull[lane] < CW_PULLS ? L.npull[lane] : CW_PULLS;
+                    for (int e = 0; e < np; e++) cw_init_slot(W, L.psl[lane][e], L.pull[lane][e], L.lab[lane], 0);
+                    rs_add_edge(W, wc, L.mem[lane][0], L.mem[lane][0]);
+                }
+                break;
+            }
         }
         __syncthreads();
     }
@@ -349,9 +447,11 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
 
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
 {
+    static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
+    const int nb = nb_env > 0 ? nb_env : CW_BLOCKS;
     switch (c->P.geometry) {
-    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3(CW_BLOCKS), dim3(64), 0, c->stream, A); break;
-    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3(CW_BLOCKS), dim3(64), 0, c->stream, A); break;
+    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3(nb), dim3(64), 0, c->stream, A); break;
+    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3(nb), dim3(64), 0, c->stream, A); break;
     }
     return hipGetLastError();
 }

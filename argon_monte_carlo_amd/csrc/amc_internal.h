@@ -124,6 +124,7 @@ struct amc_ctx {
     int *d_lay;               // device copy of the three layer tables, contiguous
     amc_lists B;
     amc_resolve_ws W;
+    char *w_slab;             // the one allocation W's arrays are carved from
     amc_temp_ws T;
     amc_temp_dev_ws TD;
     bool allpairs;

@@ -30,6 +30,7 @@
 // a small sweep (a large one is committed by the wide k_commit).  When the wide kernel left nothing and found nothing
 // — the usual case — this kernel is the commit alone.  Without a detection grid (single cells, N <= 4096: MODE 2)
 // everything, brute-force validation included, happens here.
+#include <stdlib.h>
 #include "amc_resolve_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     if (ncand == 0) return;     // uniform: nothing to resolve this sweep
 
     const bool wide = wide_ns >= 0;
+    const int gen_off = wide ? 16 : 0;          // (the wide kernel tags its own re-emulations of a cluster with rounds 1, 2, 3)
     const bool mono = (MODE == 2) || A.force_mono;      // commit in this kernel
     {
         int mine = 0;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             W.edge_b[k] = eb < -1 ? -(eb + 2) : W.slot_of[eb];
         }
         edges_conv = nedges;
-        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }
+        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds + gen_off; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }
         __syncthreads();
         if (first) {
             // ---- connected components of what is left by label propagation (label = lowest slot id of the cluster) ---------------
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         ns_lab = ns;
         __syncthreads();
         for (int s = tid; s < ns; s += RS_T)
-            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds; atomicAnd(&W.sl_hits[s], 0); }
+            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds + gen_off; atomicAnd(&W.sl_hits[s], 0); }
         __syncthreads();
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
         unsigned long long *keys = lds_keys;
@@ -547,6 +549,11 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     amc_prof_begin(c, AMC_K_PAIRS_WIDE);
     amc_launch_clusters_wide(c, Aw);
     amc_prof_end(c);
+    if (getenv("AMC_CW_TWICE")) {       // timing experiment only (the results of the step are garbage): the same kernel again, warm
+        amc_prof_begin(c, AMC_K_VALIDATE);
+        amc_launch_clusters_wide(c, Aw);
+        amc_prof_end(c);
+    }
     amc_prof_begin(c, AMC_K_RESOLVE);
     hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, Aw);
     if (!c->plan_split) return;

@@ -32,6 +32,20 @@ struct rs_args {
     int wide_plan;            // k_clusters_wide ran before this kernel: start from the counters it left in W.wctl
 };
 
+// The argument block of the resolve kernels is 1.3 KB.  Read field by field from the kernarg segment it costs every wave a
+// long train of dependent scalar loads (and SGPR spills) at the head of every phase — measured: most of these
+// latency-bound kernels' time.  Each workgroup therefore copies the block into LDS once, with one coalesced vector
+// load, and reads the fields from there.  The kernel's only formal parameter is the block (offset 0 of the segment).
+#define RS_STAGE_ARGS(A)                                                                              \
+    __shared__ rs_args s_args__;                                                                      \
+    {                                                                                                 \
+        const int *src__ = (const int *)__builtin_amdgcn_kernarg_segment_ptr();                       \
+        int *dst__ = (int *)&s_args__;                                                                \
+        for (int i__ = threadIdx.x; i__ < (int)(sizeof(rs_args) / 4); i__ += blockDim.x) dst__[i__] = src__[i__];   \
+        __syncthreads();                                                                              \
+    }                                                                                                 \
+    const rs_args &A = s_args__
+
 struct amc_ctx;
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A);      // amc_clusters.hip
 
@@ -117,6 +131,7 @@ struct rs_wide {
     int *nitems;
     int cap;
     int own;
+    int gen;                  // round tag of this emulation (the wide kernel re-emulates a cluster that pulled a particle in)
     int *it0;                 // where the owner's first work item went (-1: none yet)
     int *unval;               // set when a hit got entries the wave cannot publish: the ordered workgroup redoes the cluster
 };
@@ -153,7 +168,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     }
     const bool room = h + 1 < W.max_hist;
     if (!room) sh->ovf = 1;
-    const int gen = sh->cur_round;
+    const int gen = wd ? wd->gen : sh->cur_round;
     if (room) { W.ev_gen[h] = 0; W.ev_gen[h + 1] = 0; }
     auto emit = [&](int which, double tot, double px, double py, double pz) {
         if (!room) return;
