@@ -278,24 +278,17 @@ int amc_create(amc_ctx **out, const amc_params *p)
                     off += sizeof(T) * std::max<size_t>(count, 1);
                 };
                 take(&W.ctl, 64); take(&W.wctl, 64);
-                take(&W.cand_i, (size_t)W.max_cand); take(&W.cand_j, (size_t)W.max_cand);
-                take(&W.cand_si, (size_t)W.max_cand); take(&W.cand_sj, (size_t)W.max_cand);
-                take(&W.cand4, (size_t)W.max_cand); take(&W.cand_done, (size_t)W.max_cand);
-                take(&W.cst, (size_t)22 * W.max_cand);
-                take(&W.sl_p, ms); take(&W.sl_label, ms); take(&W.sl_tmp, ms); take(&W.order, ms);
+                take(&W.cand4, (size_t)W.max_cand); take(&W.cand_s, (size_t)W.max_cand);
+                take(&W.cst, (size_t)RS_CST_DOUBLES * W.max_cand);
+                take(&W.sl_meta, ms); take(&W.sl_hits, ms); take(&W.sl_moved, ms);
+                take(&W.sl_state, (size_t)RS_SLOT_DOUBLES * ms);
+                take(&W.sl_label, ms); take(&W.sl_tmp, ms); take(&W.sl_dirty, ms); take(&W.order, ms);
                 take(&W.sl_key, (size_t)next_pow2(W.max_slots));
-                double **sl[] = {&W.sl_x, &W.sl_y, &W.sl_z, &W.sl_vx, &W.sl_vy, &W.sl_vz, &W.sl_d, &W.sl_dx, &W.sl_dy, &W.sl_dz};
-                for (auto pp : sl) take(pp, ms);
-                take(&W.sl_flag, ms); take(&W.sl_moved, ms); take(&W.sl_dirty, ms);
-                take(&W.sl_gen, ms); take(&W.sl_hits, ms);
                 for (int k = 0; k < 10; k++) take(&W.cw_d[k], ms);
                 take(&W.cw_tmp, ms); take(&W.cw_pidx, ms); take(&W.cw_slot, ms); take(&W.cw_flag, ms); take(&W.cw_moved, ms);
                 take(&W.edge_a, (size_t)W.max_edges); take(&W.edge_b, (size_t)W.max_edges);
                 take(&W.hist, (size_t)W.max_hist); take(&W.ov_next, (size_t)W.max_hist);
-                take(&W.ev_phase, (size_t)W.max_hist); take(&W.ev_i, (size_t)W.max_hist);
-                take(&W.ev_j, (size_t)W.max_hist); take(&W.ev_which, (size_t)W.max_hist);
-                take(&W.ev_cell, (size_t)W.max_hist); take(&W.ev_val, (size_t)4 * W.max_hist);
-                take(&W.ev_gen, (size_t)W.max_hist); take(&W.ev_slot, (size_t)W.max_hist);
+                take(&W.ev_gen, (size_t)W.max_hist); take(&W.ev, (size_t)W.max_hist);
                 take(&W.adj_head, n); take(&W.slot_of, n);
                 return (off + 255) & ~(size_t)255;
             };

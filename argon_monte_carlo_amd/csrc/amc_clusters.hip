@@ -68,9 +68,12 @@ AMC_DEV void cw_reserve2(int *ca, int na, int *cb, int nb, int &base_a, int &bas
 
 AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label, int gen)
 {
-    W.slot_of[p] = s; W.sl_p[s] = p; W.sl_label[s] = label; W.sl_moved[s] = 0;
-    // (write-through: a prober of another workgroup that meets one of this slot's history entries compares rounds)
-    __hip_atomic_store(&W.sl_gen[s], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    W.slot_of[p] = s; W.sl_moved[s] = 0;
+    // (particle, label, round, -) written through: a prober of another workgroup that meets one of this slot's history
+    // entries compares rounds
+    unsigned long long *m = (unsigned long long *)&W.sl_meta[s];
+    __hip_atomic_store(m + 0, ((unsigned long long)(unsigned int)label << 32) | (unsigned int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(m + 1, (unsigned long long)(unsigned int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     atomicAnd(&W.sl_hits[s], 0);        // (an atomic, like the increments that follow)
 }
 
@@ -158,7 +161,7 @@ AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item 
                     return;
                 }
                 if (s >= W.max_slots) wc->ovf = 1;
-                else { W.sl_p[s] = idx; W.sl_label[s] = s; W.sl_moved[s] = 0; W.sl_gen[s] = 0; atomicAnd(&W.sl_hits[s], 0); }
+                else { W.sl_meta[s] = make_int4(idx, s, 0, 0); W.sl_moved[s] = 0; atomicAnd(&W.sl_hits[s], 0); }
                 W.slot_of[idx] = s < W.max_slots ? s : -1;      // too many at once: a plain merge edge instead
             }
         }
@@ -171,7 +174,7 @@ AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item 
         for (int m = 0; m < nm; m++)
             if (L.msl[own][m] == s2) return;
         // position of an emulation that was redone since?  (its owner raised the slot's round before it published anew)
-        if (rs_hist_gen(o) != __hip_atomic_load(&W.sl_gen[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (rs_hist_gen(o) != __hip_atomic_load(((int *)&W.sl_meta[s2]) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         rs_add_edge(W, wc, me.p, -(s2 + 2));                    // (the other end as a slot)
     };
     // first element of every list before any is examined (the probe is a chain of dependent round trips)
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
             const int pj = c4.y, pi = c4.x, sj = sbase, si = sbase + 1;
             cw_init_slot(W, sj, pj, sj, 1);
             cw_init_slot(W, si, pi, sj, 1);
-            W.cand_sj[k] = sj; W.cand_si[k] = si; W.cand_done[k] = 1;
+            W.cand_s[k] = make_int4(si, sj, 1, 0);
             int pre_next = hbase, unval = 0;
             rs_wide wd;
             wd.pre_next = &pre_next; wd.pre_end = hbase + 2; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
@@ -376,10 +379,11 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                 if (g == 0)
                     for (int e = lane; e < ncs; e += 64) {
                         const int c = L.cnd[src][e];
-                        const int pi = W.cand_i[c], pj = W.cand_j[c];
+                        const int4 cc = W.cand4[c];
+                        const int pi = cc.x, pj = cc.y;
                         int ai = 0, aj = 0;
                         for (int t = 0; t < m; t++) { if (L.mem[src][t] == pi) ai = t; if (L.mem[src][t] == pj) aj = t; }
-                        W.cand_si[c] = L.msl[src][ai]; W.cand_sj[c] = L.msl[src][aj]; W.cand_done[c] = 1;
+                        W.cand_s[c] = make_int4(L.msl[src][ai], L.msl[src][aj], 1, 0);
                     }
                 __syncthreads();
                 rs_wide wd;

@@ -44,29 +44,26 @@ __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x,
 // a larger connected component by the wave of its lowest candidate.
 struct amc_adj {
     unsigned long long *head;   // [n]   nullptr: the graph is not needed (all-pairs mode)
-    int4 *rec;                  // [max_cand]
-    uint8_t *done;              // [max_cand]
+    int4 *rec;                  // [max_cand] (i, j, next in i's list, next in j's list)
+    int4 *sd;                   // [max_cand] (slot of i, slot of j, done, -): reset here
     unsigned int epoch;
 };
 
-AMC_DEV int amc_push_candidate(int a, int b, int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                               const amc_adj &D)
+AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt, const amc_adj &D)
 {
     const unsigned int k = atomicAdd(&cnt->cand_count, 1u);
     if (k < (unsigned)max_cand) {
         const int hi = a > b ? a : b, lo = a > b ? b : a;
-        cand_i[k] = hi;
-        cand_j[k] = lo;
+        int4 r;
+        r.x = hi; r.y = lo; r.z = -1; r.w = -1;
         if (D.head) {
             const unsigned long long mine = ((unsigned long long)D.epoch << 32) | (unsigned long long)k;
             const unsigned long long oi = atomicExch(&D.head[hi], mine), oj = atomicExch(&D.head[lo], mine);
-            int4 r;
-            r.x = hi; r.y = lo;
             r.z = ((unsigned int)(oi >> 32) == D.epoch) ? (int)(unsigned int)(oi & 0xffffffffULL) : -1;
             r.w = ((unsigned int)(oj >> 32) == D.epoch) ? (int)(unsigned int)(oj & 0xffffffffULL) : -1;
-            D.rec[k] = r;
-            D.done[k] = 0;
         }
+        D.rec[k] = r;
+        D.sd[k] = make_int4(-1, -1, 0, 0);      // (slot of i, slot of j, done by the wide kernel, -)
         return (int)k;
     }
     atomicOr(&cnt->flags, 1ULL);
@@ -85,8 +82,7 @@ AMC_DEV double amc_state_elem(const amc_state &S, int p, int e)
 
 // state gather for the candidates found by the lanes of this wave, done by the WHOLE wave: lane e < 22 moves element
 // e of the pair (11 per particle), so a candidate costs one load + one store instruction instead of 44 serial ones
-AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int my_j, int max_cand,
-                             const amc_state &S, double *cst)
+AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int my_j, const amc_state &S, double *cst)
 {
     const int lane = threadIdx.x & 63;
     while (found) {
@@ -95,7 +91,7 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
         const int k = __shfl(my_k, src, 64);
         const int pi = __shfl(my_i, src, 64), pj = __shfl(my_j, src, 64);     // (i > j), straight from the finder's registers
         if (k < 0 || lane >= 22) continue;
-        cst[(size_t)lane * (size_t)max_cand + k] = amc_state_elem(S, lane / 11 ? pi : pj, lane % 11);
+        cst[(size_t)k * RS_CST_DOUBLES + lane] = amc_state_elem(S, lane / 11 ? pi : pj, lane % 11);
     }
 }
 
@@ -106,8 +102,7 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 // whatever their width, index-ordered ones at ~2e11/s — the kernel's cost is its number of random requests
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
 __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
-                                                      int *cand_i, int *cand_j, int max_cand, amc_dev_counters *cnt,
-                                                      amc_state S, double *cst, amc_adj D)
+                                                      int max_cand, amc_dev_counters *cnt, amc_state S, double *cst, amc_adj D)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
@@ -119,11 +114,11 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
                 pending = true; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
                 return;
             }
-            const int kk = amc_push_candidate((int)p, q, cand_i, cand_j, max_cand, cnt, D);
+            const int kk = amc_push_candidate((int)p, q, max_cand, cnt, D);
             if (kk >= 0) {
                 const int hi = (int)p > q ? (int)p : q, lo = (int)p > q ? q : (int)p;
                 for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
-                    cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? hi : lo, e % 11);
+                    cst[(size_t)kk * RS_CST_DOUBLES + e] = amc_state_elem(S, e / 11 ? hi : lo, e % 11);
             }
         };
         // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
@@ -181,11 +176,11 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
         const int pi0 = __shfl(my_i, src0, 64), pj0 = __shfl(my_j, src0, 64);
         double v0 = 0.0;
         if (lane < 22) v0 = amc_state_elem(S, lane / 11 ? pi0 : pj0, lane % 11);
-        if (pending) my_k = amc_push_candidate(my_i, my_j, cand_i, cand_j, max_cand, cnt, D);
+        if (pending) my_k = amc_push_candidate(my_i, my_j, max_cand, cnt, D);
         const int k0 = __shfl(my_k, src0, 64);
-        if (k0 >= 0 && lane < 22) cst[(size_t)lane * (size_t)max_cand + k0] = v0;
+        if (k0 >= 0 && lane < 22) cst[(size_t)k0 * RS_CST_DOUBLES + lane] = v0;
         found &= found - 1;
-        if (found) amc_wave_gather(found, my_k, my_i, my_j, max_cand, S, cst);
+        if (found) amc_wave_gather(found, my_k, my_i, my_j, S, cst);
     }
 }
 
@@ -193,8 +188,8 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 #define AP_T 256
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ z, int n, int ntiles, double cr2i,
-                                                          int *cand_i, int *cand_j, int max_cand,
-                                                          amc_dev_counters *cnt, amc_state S, double *cst, amc_adj D)
+                                                          int max_cand, amc_dev_counters *cnt, amc_state S, double *cst,
+                                                          amc_adj D)
 {
     // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -219,10 +214,10 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
         const double d2 = ex * ex + ey * ey + ez * ez;
         if (d2 < cr2i) {
-            const int kk = amc_push_candidate(i, j0 + k, cand_i, cand_j, max_cand, cnt, D);
+            const int kk = amc_push_candidate(i, j0 + k, max_cand, cnt, D);
             if (kk >= 0)
                 for (int e = 0; e < 22; e++)
-                    cst[(size_t)e * (size_t)max_cand + kk] = amc_state_elem(S, e / 11 ? i : (j0 + k), e % 11);
+                    cst[(size_t)kk * RS_CST_DOUBLES + e] = amc_state_elem(S, e / 11 ? i : (j0 + k), e % 11);
         }
     }
 }
@@ -252,17 +247,17 @@ hipError_t amc_launch_detect(amc_ctx *c)
     // kernel writes into host-mapped memory; it may lag by a step): a small sweep is committed by the ordered
     // workgroup itself, a large one by the wide commit kernel
     c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
-    D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.done = c->W.cand_done; D.epoch = c->sweep_epoch;
+    D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.sd = c->W.cand_s; D.epoch = c->sweep_epoch;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);
         const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
         if (nblocks > 0)
             hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
-                               c->S.z, (int)n, ntiles, cr2i, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
+                               c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
     } else {
         hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
-                           c->P.collision_range * 1.000001, c->W.cand_i, c->W.cand_j, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
+                           c->P.collision_range * 1.000001, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
     }
     amc_prof_end(c);
     return hipGetLastError();

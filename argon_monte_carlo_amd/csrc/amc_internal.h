@@ -8,6 +8,9 @@
 
 #include "amc_device.h"
 
+#define RS_SLOT_DOUBLES 12    // x y z vx vy vz d dx dy dz flag(0/1) pad  — one slot's scratch state (96 bytes)
+#define RS_CST_DOUBLES 24     // 11 of particle j, 11 of particle i, 2 pad — one candidate's gathered state (192 bytes)
+
 // ---- SoA particle state in HBM (one allocation each, float64[n]; flag uint8[n]) --------------------------------
 struct amc_state {
     double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
@@ -43,48 +46,53 @@ struct amc_lists {
 // up (a coalesced slot_of[] read per particle) instead of a scattered commit from one workgroup
 struct amc_lazy {
     int *slot_of;
-    const double *x, *y, *z, *vx, *vy, *vz, *d, *dx, *dy, *dz;
-    const uint8_t *flag, *moved;
+    const double *state;      // [slots][RS_SLOT_DOUBLES]
+    const uint8_t *moved;
     int enabled;
 };
 
 // ---- resolve scratch ---------------------------------------------------------------------------------------------
+// The resolve kernels are chains of dependent, scattered accesses by a few waves: what they cost is the number of
+// memory round trips and of DISTINCT arrays (every array is a base pointer to fetch and to keep in scalar registers).
+// So what one thread handles at a time is ONE record (array of structures); only what the ordered workgroup scans in
+// bulk stays a plain array.
+struct rs_event {             // a completed free path found by an emulation (64 bytes), emitted at commit
+    int phase, i, j, which;
+    long long cell;
+    int slot, pad;
+    double val[4];            // total, x, y, z
+};
 struct amc_resolve_ws {
-    int *cand_i, *cand_j;     // candidate pairs, i > j (particle indices)
-    int *cand_si, *cand_sj;   // the same pairs as slot ids (filled by the resolve kernel)
+    // candidates: cand4[k] = (i, j, next candidate in i's list, next candidate in j's list), i > j (particle indices);
+    // cand_s[k] = (slot of i, slot of j, done by the wide kernel, -); cst = state of both particles, gathered by detect
+    int4 *cand4, *cand_s;
+    double *cst;              // [max_cand][RS_CST_DOUBLES]
     int max_cand;
+    unsigned long long *adj_head;   // [n] (sweep epoch << 32) | last candidate pushed that touches the particle
     int *slot_of;             // [n] particle -> slot or -1
     int max_slots;
-    int *sl_p, *sl_label, *sl_tmp;                 // [max_slots]
+    int4 *sl_meta;            // [max_slots] (particle, cluster label at the wide kernel's hand-over, round of the last emulation, -)
+    int *sl_hits;             // collisions (low half) and failed contact solves (high half) counted on the slot: atomics only
+    uint8_t *sl_moved;        // the slot's scratch state differs from the particle arrays
+    double *sl_state;         // [max_slots][RS_SLOT_DOUBLES]
+    int *sl_label, *sl_tmp;   // labels / sizes of the ordered workgroup when they do not fit its LDS
+    uint8_t *sl_dirty;
     unsigned long long *sl_key;                    // sort keys (label<<32 | particle)
-    int *order;                                    // slots sorted by (label, particle)
-    double *sl_x, *sl_y, *sl_z, *sl_vx, *sl_vy, *sl_vz, *sl_d, *sl_dx, *sl_dy, *sl_dz;
-    uint8_t *sl_flag, *sl_moved, *sl_dirty;
-    int *sl_gen, *sl_hits;    // round in which the slot's cluster was last emulated; collisions counted on the slot
-    int *ev_gen, *ev_slot;    // round tags: results of a re-emulated cluster are superseded, not erased
+    int *order;
     double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
     int *cw_tmp, *cw_pidx, *cw_slot;
     uint8_t *cw_flag, *cw_moved;
-    int *edge_a, *edge_b;     // extra merge edges (slots) found by verification
+    int *edge_a, *edge_b;     // merge edges found by validation (particles, or slots encoded as -(slot + 2))
     int max_edges;
     double4 *hist;            // position history of the sweep: (x, y, z, slot | round << 32) per new position
     int max_hist;
     int *ov_head, *ov_next;   // overlay lists of history entries per grid cell ([ncells], [max_hist])
-    // completed paths found by the emulations, emitted at commit.  Events share the index space of the history: a hit
-    // owns the entry pair (h, h + 1) — h for particle j, h + 1 for particle i — and its (at most two) events sit at the
-    // same two indices; ev_gen == 0 marks "no event" ([max_hist] each)
-    int *ev_phase, *ev_i, *ev_j, *ev_which;
-    long long *ev_cell;
-    double *ev_val;           // [max_hist][4]
+    // Events share the index space of the history: a hit owns the entry pair (h, h + 1) — h for particle j, h + 1 for
+    // particle i — and its (at most two) events sit at the same two indices; ev_gen == 0 marks "no event"
+    int *ev_gen;              // [max_hist] round of the emulation that produced the event
+    rs_event *ev;             // [max_hist]
     int *ctl;                 // rs_shared in global memory: hand-over between the resolve kernels
     int *wctl;                // rs_shared of the wide cluster kernel (counters it advanced before the ordered workgroup starts)
-    // candidate graph, built by the detect kernel with one 64-bit exchange per endpoint (no clearing: epoch tags):
-    //   adj_head[p] = (sweep epoch << 32) | last candidate pushed that touches particle p
-    //   cand4[k]    = (i, j, next candidate in i's list, next candidate in j's list)
-    unsigned long long *adj_head;   // [n]
-    int4 *cand4;              // [max_cand]
-    uint8_t *cand_done;       // [max_cand] candidate belongs to a cluster the wide kernel emulated (cleared by detect)
-    double *cst;              // [22][max_cand] state of both particles of every candidate, gathered by detect
 };
 
 // energised-wall hand-over buffers (amc_energised.hip)

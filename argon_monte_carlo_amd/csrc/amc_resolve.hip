@@ -81,7 +81,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
             sh.nhist = wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges; sh.nclusters = wc->nclusters;
             wide_dirty = wc->dirty;
-            wide_ns = wc->active ? sh.nslots : -1;              // (>= 0: the wide kernel ran, W.cand_done is valid)
+            wide_ns = wc->active ? sh.nslots : -1;              // (>= 0: the wide kernel ran, W.cand_s[k].z is valid)
             wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
             wc->nslots = 0; wc->nhist = 0; wc->nedges = 0; wc->nfp = 0; wc->ovf = 0; wc->dirty = 0; wc->nclusters = 0;
             wc->active = 0; wc->cur_round = 1;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     const bool mono = (MODE == 2) || A.force_mono;      // commit in this kernel
     {
         int mine = 0;
-        for (int k = tid; k < ncand; k += RS_T) mine += !(wide && W.cand_done[k]);
+        for (int k = tid; k < ncand; k += RS_T) mine += !(wide && W.cand_s[k].z);
         if (mine) atomicAdd(&s_left, mine);
     }
     __syncthreads();
@@ -114,7 +114,6 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_slots V;
-    V.p = W.sl_p;
     unsigned char *vdirty;
     // (the slot arrays in global memory hold W.max_slots entries: labels in LDS must not let validation claim more)
     if ((wide ? wide_ns : 0) + 2 * nleft + 256 <= RS_NS) { V.label = s_label; V.size = s_size; V.cap = RS_NS < W.max_slots ? RS_NS : W.max_slots; vdirty = s_dirty; }
@@ -129,15 +128,16 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         // ---- slots for the endpoints of the candidates that are left; candidates become slot pairs ----------------------
         for (int k = tid; k < ncand; k += RS_T) {
-            if (wide && W.cand_done[k]) continue;           // its cluster was emulated wide: slots, state and history exist
-            rs_claim_slot(W, &sh, V.cap, W.cand_i[k]);
-            rs_claim_slot(W, &sh, V.cap, W.cand_j[k]);
+            if (wide && W.cand_s[k].z) continue;            // its cluster was emulated wide: slots, state and history exist
+            const int4 c4 = W.cand4[k];
+            rs_claim_slot(W, &sh, V.cap, c4.x);
+            rs_claim_slot(W, &sh, V.cap, c4.y);
         }
         __syncthreads();
         for (int k = tid; k < ncand; k += RS_T) {
-            if (wide && W.cand_done[k]) continue;
-            W.cand_si[k] = W.slot_of[W.cand_i[k]];
-            W.cand_sj[k] = W.slot_of[W.cand_j[k]];
+            if (wide && W.cand_s[k].z) continue;
+            const int4 c4 = W.cand4[k];
+            W.cand_s[k] = make_int4(W.slot_of[c4.x], W.slot_of[c4.y], 0, 0);
         }
         __syncthreads();
     }
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             if (first) {
                 // slots of the wide kernel carry the labels it wrote (first slot of the cluster) and are NOT emulated
                 // again in this round; everything claimed here starts as its own cluster and is
-                if (V.label != W.sl_label || s >= wide_ns) V.label[s] = (s < wide_ns) ? W.sl_label[s] : s;
+                V.label[s] = (s < wide_ns) ? W.sl_meta[s].y : s;
             } else if (s >= ns_lab) {
                 V.label[s] = s;                             // claimed by the previous validation
             }
@@ -177,8 +177,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             for (;;) {
                 int changed = 0;
                 for (int k = tid; k < ncand; k += RS_T) {
-                    if (wide && W.cand_done[k]) continue;
-                    const int sa = W.cand_si[k], sb = W.cand_sj[k];
+                    const int4 cs = W.cand_s[k];
+                    if (wide && cs.z) continue;
+                    const int sa = cs.x, sb = cs.y;
                     if (sa < 0 || sb < 0 || sa >= ns || sb >= ns) continue;
                     const int la = V.label[sa], lb = V.label[sb];
                     if (la < lb) { atomicMin(&V.label[sb], la); changed = 1; }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         ns_lab = ns;
         __syncthreads();
         for (int s = tid; s < ns; s += RS_T)
-            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; W.sl_gen[s] = rounds + gen_off; atomicAnd(&W.sl_hits[s], 0); }
+            if (vdirty[V.label[s]]) { W.sl_moved[s] = 0; ((int *)&W.sl_meta[s])[2] = rounds + gen_off; atomicAnd(&W.sl_hits[s], 0); }
         __syncthreads();
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
         unsigned long long *keys = lds_keys;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             if (V.label[s] == s) atomicAdd(&sh.nclusters, 1);
             if (V.size[V.label[s]] >= 3 && vdirty[V.label[s]]) {
                 const int k = atomicAdd(&sh.ncomplex, 1);
-                const unsigned long long key = ((unsigned long long)(unsigned)V.label[s] << 32) | (unsigned)V.p[s];
+                const unsigned long long key = ((unsigned long long)(unsigned)V.label[s] << 32) | (unsigned)W.sl_meta[s].x;
                 if (k < RS_SORT_LDS) keys[k] = key; else W.sl_key[k] = key;
             }
         }
@@ -292,11 +293,12 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             // ---- two-particle clusters straight from the candidate list, both particles in registers ------------------------
             const int t0 = split ? tid - 64 : tid, tstride = split ? RS_T - 64 : RS_T;
             for (int k = t0; k < ncand; k += tstride) {
-                if (first && wide && W.cand_done[k]) continue;                     // emulated (and valid) by the wide kernel
-                const int si = W.cand_si[k], sj = W.cand_sj[k];
+                const int4 cs = W.cand_s[k];
+                if (first && wide && cs.z) continue;                                // emulated (and valid) by the wide kernel
+                const int si = cs.x, sj = cs.y;
                 if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
                 if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
-                rs_emulate_pair<GEOM>(A, &sh, k, W.cand_j[k], W.cand_i[k], sj, si);
+                { const int4 c4 = W.cand4[k]; rs_emulate_pair<GEOM>(A, &sh, k, c4.y, c4.x, sj, si); }
             }
         }
         RS_STAMP(7);
@@ -372,13 +374,13 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const double4 hr = W.hist[h];
                 if (rs_hist_gen(hr) == 0) continue;
                 const int sme = rs_hist_slot(hr);
-                if (idx == V.p[sme]) continue;
+                if (idx == W.sl_meta[sme].x) continue;
                 const double ex = A.S.x[idx] - hr.x, ey = A.S.y[idx] - hr.y, ez = A.S.z[idx] - hr.z;
                 if (ex * ex + ey * ey + ez * ez < cr2i) {
                     const int so = W.slot_of[idx];
                     if (so >= 0 && so < ns && V.label[so] == V.label[sme]) continue;
                     if (so < 0) rs_claim_slot(W, &sh, V.cap, idx);
-                    rs_add_edge(W, &sh, V.p[sme], idx);
+                    rs_add_edge(W, &sh, W.sl_meta[sme].x, idx);
                 }
             }
             for (long long w = tid; w < (long long)(nh - hb) * nh; w += RS_T) {
@@ -387,10 +389,10 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const double4 ha = W.hist[h], hb2 = W.hist[h2];
                 if (rs_hist_gen(ha) == 0) continue;
                 const int s1 = rs_hist_slot(ha), s2 = rs_hist_slot(hb2);
-                if (rs_hist_gen(hb2) != W.sl_gen[s2]) continue;
+                if (rs_hist_gen(hb2) != W.sl_meta[s2].z) continue;
                 if (V.label[s1] == V.label[s2]) continue;
                 const double ex = hb2.x - ha.x, ey = hb2.y - ha.y, ez = hb2.z - ha.z;
-                if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, V.p[s1], V.p[s2]);
+                if (ex * ex + ey * ey + ez * ez < cr2i) rs_add_edge(W, &sh, W.sl_meta[s1].x, W.sl_meta[s2].x);
             }
         }
         __syncthreads();
@@ -416,12 +418,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         for (int h = tid; h < nh_all; h += RS_T) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;
     const bool defer = ok && A.defer_commit;        // the next streaming pass reads the slot arrays through slot_of[]
     for (int s = tid; s < ns && !defer; s += RS_T) {
-        const int p = V.p[s];
+        const int p = W.sl_meta[s].x;
         if (ok && W.sl_moved[s]) {
-            A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
-            A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
-            A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
-            A.S.flag[p] = W.sl_flag[s];
+            rs_apply_slot(W, A.S, s, p);
         }
         W.slot_of[p] = -1;
     }
@@ -431,11 +430,11 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         for (int e = tid; e < nh_all; e += RS_T) {
             const int g = W.ev_gen[e];
             if (g == 0) continue;                                           // no completed path at this entry
-            if (g != W.sl_gen[W.ev_slot[e]]) continue;                      // event of an emulation that was redone
-            const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];
+            const rs_event ev = W.ev[e];
+            if (g != W.sl_meta[ev.slot].z) continue;                      // event of an emulation that was redone
+            const int owner = ev.which ? ev.i : ev.j;
             if (owner < A.lo || owner >= A.hi) continue;
-            amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
-                     W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
+            amc_emit(A.O, ev.phase, ev.cell, ev.i, ev.j, ev.which, ev.val[0], ev.val[1], ev.val[2], ev.val[3]);
         }
         for (int s2 = tid; s2 < ns; s2 += RS_T) {
             // the counts were updated by atomics (performed in L2): read them there too, not from this CU's L1
@@ -476,13 +475,10 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         // amc_flush: deferred results -> particle arrays (single block; the host clears its pending flag)
         const int ns = ctl->lazy_ns < W.max_slots ? ctl->lazy_ns : W.max_slots;
         for (int s = gtid; s < ns; s += gstride) {
-            const int p = W.sl_p[s];
+            const int p = W.sl_meta[s].x;
             if (W.slot_of[p] != s) continue;            // consumed by a streaming pass already
             if (W.sl_moved[s]) {
-                A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
-                A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
-                A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
-                A.S.flag[p] = W.sl_flag[s];
+                rs_apply_slot(W, A.S, s, p);
             }
             W.slot_of[p] = -1;
         }
@@ -495,14 +491,11 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
     int my_hits = 0, my_fp = 0;
     for (int s = gtid; s < ns; s += gstride) {
-        const int p = W.sl_p[s];
+        const int p = W.sl_meta[s].x;
         if (ok && A.count_pp) { const int hs = W.sl_hits[s]; my_hits += hs & 0xffff; my_fp += hs >> 16; }
         if (defer) continue;
         if (ok && W.sl_moved[s]) {
-            A.S.x[p] = W.sl_x[s]; A.S.y[p] = W.sl_y[s]; A.S.z[p] = W.sl_z[s];
-            A.S.vx[p] = W.sl_vx[s]; A.S.vy[p] = W.sl_vy[s]; A.S.vz[p] = W.sl_vz[s];
-            A.S.d[p] = W.sl_d[s]; A.S.dx[p] = W.sl_dx[s]; A.S.dy[p] = W.sl_dy[s]; A.S.dz[p] = W.sl_dz[s];
-            A.S.flag[p] = W.sl_flag[s];
+            rs_apply_slot(W, A.S, s, p);
         }
         W.slot_of[p] = -1;
     }
@@ -514,11 +507,11 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         for (int e = gtid; e < nh; e += gstride) {
             const int g = W.ev_gen[e];
             if (g == 0) continue;                                         // no completed path at this entry
-            if (g != W.sl_gen[W.ev_slot[e]]) continue;                    // event of an emulation that was redone since
-            const int owner = W.ev_which[e] ? W.ev_i[e] : W.ev_j[e];      // the particle whose free path completed
+            const rs_event ev = W.ev[e];
+            if (g != W.sl_meta[ev.slot].z) continue;                    // event of an emulation that was redone since
+            const int owner = ev.which ? ev.i : ev.j;      // the particle whose free path completed
             if (owner < A.lo || owner >= A.hi) continue;
-            amc_emit(A.O, W.ev_phase[e], W.ev_cell[e], W.ev_i[e], W.ev_j[e], W.ev_which[e], W.ev_val[4 * e + 0],
-                     W.ev_val[4 * e + 1], W.ev_val[4 * e + 2], W.ev_val[4 * e + 3]);
+            amc_emit(A.O, ev.phase, ev.cell, ev.i, ev.j, ev.which, ev.val[0], ev.val[1], ev.val[2], ev.val[3]);
         }
     for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // overlay entries of this sweep
     if (gtid == 0) {

@@ -75,9 +75,17 @@ AMC_DEV amc_particle rs_load_particle(const amc_state &S, int p)
 }
 AMC_DEV void rs_store_slot(const amc_resolve_ws &W, int s, const amc_particle &q)
 {
-    W.sl_x[s] = q.x; W.sl_y[s] = q.y; W.sl_z[s] = q.z; W.sl_vx[s] = q.vx; W.sl_vy[s] = q.vy; W.sl_vz[s] = q.vz;
-    W.sl_d[s] = q.d; W.sl_dx[s] = q.dx; W.sl_dy[s] = q.dy; W.sl_dz[s] = q.dz; W.sl_flag[s] = q.flag ? 1 : 0;
+    double *t = W.sl_state + (size_t)s * RS_SLOT_DOUBLES;          // one 96-byte record
+    t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.vx; t[4] = q.vy; t[5] = q.vz;
+    t[6] = q.d; t[7] = q.dx; t[8] = q.dy; t[9] = q.dz; t[10] = q.flag ? 1.0 : 0.0;
     W.sl_moved[s] = 1;
+}
+// scratch state of a slot -> the particle arrays (commit)
+AMC_DEV void rs_apply_slot(const amc_resolve_ws &W, const amc_state &S, int s, int p)
+{
+    const double *t = W.sl_state + (size_t)s * RS_SLOT_DOUBLES;
+    S.x[p] = t[0]; S.y[p] = t[1]; S.z[p] = t[2]; S.vx[p] = t[3]; S.vy[p] = t[4]; S.vz[p] = t[5];
+    S.d[p] = t[6]; S.dx[p] = t[7]; S.dy[p] = t[8]; S.dz[p] = t[9]; S.flag[p] = t[10] != 0.0 ? 1 : 0;
 }
 AMC_DEV amc_particle rs_load_work(const rs_work &K, int w)
 {
@@ -173,9 +181,10 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     auto emit = [&](int which, double tot, double px, double py, double pz) {
         if (!room) return;
         const int e = h + which;
-        W.ev_phase[e] = phase; W.ev_cell[e] = cell; W.ev_i[e] = pi; W.ev_j[e] = pj; W.ev_which[e] = which;
-        W.ev_slot[e] = si;
-        W.ev_val[4 * e + 0] = tot; W.ev_val[4 * e + 1] = px; W.ev_val[4 * e + 2] = py; W.ev_val[4 * e + 3] = pz;
+        rs_event ev;
+        ev.phase = phase; ev.i = pi; ev.j = pj; ev.which = which; ev.cell = cell; ev.slot = si; ev.pad = 0;
+        ev.val[0] = tot; ev.val[1] = px; ev.val[2] = py; ev.val[3] = pz;
+        W.ev[e] = ev;                   // one 64-byte record
         W.ev_gen[e] = gen;
     };
     const int fail = amc_collide(p1, p2, A.P.collision_range, A.P.argon_mass, emit);
@@ -283,11 +292,10 @@ AMC_DEV int rs_next_common(double v1, double v2, double d, double inv_d, double 
 // ---- two-particle cluster: literal emulation with both particles in registers -----------------------------------------
 AMC_DEV amc_particle rs_load_cst(const amc_resolve_ws &W, int k, int which)
 {
-    const size_t m = (size_t)W.max_cand;
-    const double *t = W.cst + (size_t)(11 * which) * m + k;
+    const double *t = W.cst + (size_t)k * RS_CST_DOUBLES + 11 * which;      // one 192-byte record per candidate
     amc_particle q;
-    q.x = t[0 * m]; q.y = t[1 * m]; q.z = t[2 * m]; q.vx = t[3 * m]; q.vy = t[4 * m]; q.vz = t[5 * m];
-    q.d = t[6 * m]; q.dx = t[7 * m]; q.dy = t[8 * m]; q.dz = t[9 * m]; q.flag = t[10 * m] != 0.0;
+    q.x = t[0]; q.y = t[1]; q.z = t[2]; q.vx = t[3]; q.vy = t[4]; q.vz = t[5];
+    q.d = t[6]; q.dx = t[7]; q.dy = t[8]; q.dz = t[9]; q.flag = t[10] != 0.0;
     return q;
 }
 
@@ -457,7 +465,7 @@ AMC_DEV void rs_bitonic(unsigned long long *keys, int m)
 // slot bookkeeping: particle of the slot (global), cluster label = lowest slot id of the cluster and cluster size
 // (LDS when the sweep is small enough — the usual case — else the global work space)
 struct rs_slots {
-    int *p, *label, *size;
+    int *label, *size;
     int cap;
 };
 
@@ -468,7 +476,7 @@ AMC_DEV void rs_claim_slot(const amc_resolve_ws &W, rs_shared *sh, int cap, int 
     if (old == -1) {
         const int s = atomicAdd(&sh->nslots, 1);
         if (s < cap) {
-            W.sl_p[s] = p;
+            W.sl_meta[s] = make_int4(p, s, 0, 0);
             W.slot_of[p] = s;
         } else {
             sh->ovf = 1;
@@ -626,7 +634,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const double4 me = W.hist[h];
     if (rs_hist_gen(me) == 0) return;               // the pair of a hit that failed (no new position)
     const int sme = rs_hist_slot(me);
-    const int pme = W.sl_p[sme];
+    const int pme = W.sl_meta[sme].x;
     const int lme = label[sme];
     const double x = me.x, y = me.y, z = me.z;
     // only the cells overlapped by the collision_range box around the new position can hold a partner (2 to 3 on
@@ -670,10 +678,10 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     };
     auto overlay_entry = [&](const double4 &o) {
         const int s2 = rs_hist_slot(o);
-        if (rs_hist_gen(o) != W.sl_gen[s2]) return;       // position of an emulation that was redone since
+        if (rs_hist_gen(o) != W.sl_meta[s2].z) return;    // position of an emulation that was redone since
         if (label[s2] == lme) return;
         const double ax = o.x - x, ay = o.y - y, az = o.z - z;
-        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_p[s2]);
+        if (ax * ax + ay * ay + az * az < cr2i) rs_add_edge(W, cnt, pme, W.sl_meta[s2].x);
     };
     // pre-sweep positions of the particles binned into those cells
 #pragma unroll

@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
         if (sl >= 0) {
             L.slot_of[p] = -1;
             if (L.moved[sl]) {
-                q.x = L.x[sl]; q.y = L.y[sl]; q.z = L.z[sl]; q.vx = L.vx[sl]; q.vy = L.vy[sl]; q.vz = L.vz[sl];
-                q.d = L.d[sl]; q.dx = L.dx[sl]; q.dy = L.dy[sl]; q.dz = L.dz[sl]; q.flag = L.flag[sl] != 0;
+                const double *t = L.state + (size_t)sl * RS_SLOT_DOUBLES;
+                q.x = t[0]; q.y = t[1]; q.z = t[2]; q.vx = t[3]; q.vy = t[4]; q.vz = t[5];
+                q.d = t[6]; q.dx = t[7]; q.dy = t[8]; q.dz = t[9]; q.flag = t[10] != 0.0;
                 force = true;       // the particle arrays are stale: write every field back
             }
         }
@@ -150,8 +151,7 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     memset(&L, 0, sizeof L);
     if (c->lazy_pending) {              // (a shard: its own particles here, the slots of the others are cleared by the unpack)
         const amc_resolve_ws &W = c->W;
-        L.slot_of = W.slot_of; L.x = W.sl_x; L.y = W.sl_y; L.z = W.sl_z; L.vx = W.sl_vx; L.vy = W.sl_vy; L.vz = W.sl_vz;
-        L.d = W.sl_d; L.dx = W.sl_dx; L.dy = W.sl_dy; L.dz = W.sl_dz; L.flag = W.sl_flag; L.moved = W.sl_moved;
+        L.slot_of = W.slot_of; L.state = W.sl_state; L.moved = W.sl_moved;
         L.enabled = 1;
         c->lazy_pending = false;        // this pass consumes them
     }
