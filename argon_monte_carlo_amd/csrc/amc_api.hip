@@ -262,7 +262,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         long long mc = p->max_candidates > 0 ? p->max_candidates : std::max<long long>(4096, c->n / 8 + 1024);
         if (mc > 0x3fffffff) mc = 0x3fffffff;
         W.max_cand = (int)mc;
-        W.max_slots = (int)std::min<long long>(2 * mc, std::max<long long>(c->n, 2));
+        // every candidate brings two slots of its own (2k, 2k + 1); particles that join a cluster later take theirs from a counter
+        W.max_slots = (int)std::min<long long>(2 * mc + std::max<long long>(1024, mc / 2), 0x7ffffff0LL);
         W.max_edges = 4 * W.max_slots + 1024;
         W.max_hist = 8 * W.max_slots + 1024;
         // ONE allocation for the whole sweep work space: the resolve kernels are chains of dependent, scattered accesses to

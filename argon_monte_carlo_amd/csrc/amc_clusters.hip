@@ -43,26 +43,6 @@ AMC_DEV int cw_adj_head(const amc_resolve_ws &W, unsigned int epoch, int p)
     return ((unsigned int)(v >> 32) == epoch) ? (int)(unsigned int)(v & 0xffffffffULL) : -1;
 }
 
-// two wave-wide reservations, both counter increments in flight together; every lane of the wave calls
-AMC_DEV void cw_reserve2(int *ca, int na, int *cb, int nb, int &base_a, int &base_b)
-{
-    const int lane = threadIdx.x & 63;
-    int ia = na, ib = nb;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64);
-        if (lane >= o) { ia += ta; ib += tb; }
-    }
-    const int tot_a = __shfl(ia, 63, 64), tot_b = __shfl(ib, 63, 64);
-    int ba = 0, bb = 0;
-    if (lane == 0) {
-        if (tot_a) ba = atomicAdd(ca, tot_a);
-        if (tot_b) bb = atomicAdd(cb, tot_b);
-    }
-    base_a = __shfl(ba, 0, 64) + ia - na;
-    base_b = __shfl(bb, 0, 64) + ib - nb;
-}
-
 #define CW_ITERS 3          // emulations of one cluster in this kernel: the first + two after it pulled particles in
 #define CW_PULLS 4          // particles one cluster can pull in per validation
 
@@ -91,74 +71,73 @@ AMC_DEV double4 cw_load_hist(const amc_resolve_ws &W, int h)
 struct cw_lds {
     int mem[64][CW_MAXM];       // per owner lane: the particles of its cluster (ascending when emulated)
     int msl[64][CW_MAXM];       // and their slots
-    int cnd[64][CW_MAXC];       // its candidates
+    int cnd[64][CW_MAXC];       // its candidates: candidate c brings slots 2c, 2c + 1 and the history pair (2c, 2c + 1)
     int pull[64][CW_PULLS], psl[64][CW_PULLS];     // particles (and their new slots) the last validation pulled in
     int nm[64], nc[64], lab[64], npull[64];         // members, candidates, cluster label (= first slot), pulls
-    int hb[64][CW_ITERS], he[64][CW_ITERS], it0[64][CW_ITERS];   // per emulation: reserved entries [hb, he), first work item
+    int hb[64][CW_ITERS], he[64][CW_ITERS], it0[64][CW_ITERS];   // per emulation: reserved range (re-emulations), first work item
+    int used[64];               // history pairs the running emulation has taken
     int redo[64];               // the cluster must be emulated (again) by the wave
     int gen[64];                // emulations done
     cw_item item[CW_ITEMS];
     int next[CW_ITEMS];         // overlay `next` of every published item (own entries are stepped over without a load)
-    int nitems, hnext, unval;
+    int nitems, unval;
     double pool_d[10][CW_MAXM];
     int pool_tmp[CW_MAXM], pool_pidx[CW_MAXM], pool_slot[CW_MAXM];
     uint8_t pool_flag[CW_MAXM], pool_moved[CW_MAXM];
 };
 
-// probe of one published position: everything outside its cluster within the (inflated) collision range either joins
-// the cluster (a particle that is in no candidate and that nobody else has taken: the owner emulates again with it) or
-// becomes a merge edge for the ordered workgroup
-AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, double cr2i)
+// One cell of the probe of one published position: everything outside its cluster within the (inflated) collision range
+// either joins the cluster (a particle that is in no candidate and that nobody else has taken: the owner emulates again
+// with it) or becomes a merge edge for the ordered workgroup.  The (up to eight) cells of a position's box go to different
+// lanes when the wave has lanes to spare — the probe is a chain of dependent round trips plus a few hundred instructions
+// per cell, and a lone wave issues one instruction every ~2 ns.
+AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, int cell, double cr2i, int h_off)
 {
     const amc_resolve_ws &W = A.W;
     const int own = me.own, nm = L.nm[own], lab = L.lab[own];
     const double x = me.x, y = me.y, z = me.z;
-    int c_lo[4], c_hi[4], lh[8], ovh[8];
-    const int ncell = amc_grid_box_ranges(A.G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        lh[2 * k] = lh[2 * k + 1] = -1; ovh[2 * k] = ovh[2 * k + 1] = -1;
-        if (k < ncell) {
-            lh[2 * k] = amc_list_head(A.B, c_lo[k]);
-            ovh[2 * k] = __hip_atomic_load(&W.ov_head[c_lo[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c_hi[k] != c_lo[k]) {
-                lh[2 * k + 1] = amc_list_head(A.B, c_hi[k]);
-                ovh[2 * k + 1] = __hip_atomic_load(&W.ov_head[c_hi[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
     // entries of my own cluster (of this and of earlier emulations) are stepped over through the `next` values their
     // pushes returned (LDS), without a load
     auto skip_own = [&](int h2) {
-        for (;;) {
-            int r = 0;
-            for (; r < CW_ITERS; r++)
-                if (h2 >= L.hb[own][r] && h2 < L.he[own][r]) break;
-            if (r == CW_ITERS) return h2;
-            h2 = L.next[L.it0[own][r] + (h2 - L.hb[own][r])];
+        while (h2 >= 0) {
+            int t = -1;
+            if (h2 < h_off) {                               // a candidate's own pair: mine if the candidate is
+                const int c = h2 >> 1, ncs = L.nc[own];
+                for (int q = 0; q < ncs; q++)
+                    if (L.cnd[own][q] == c) { t = L.it0[own][0] + 2 * q + (h2 & 1); break; }
+            } else {
+                for (int r = 1; r < CW_ITERS; r++)
+                    if (h2 >= L.hb[own][r] && h2 < L.he[own][r]) { t = L.it0[own][r] + (h2 - L.hb[own][r]); break; }
+            }
+            if (t < 0) break;
+            h2 = L.next[t];
         }
+        return h2;
     };
-    auto member = [&](int idx) {
-        for (int m = 0; m < nm; m++)
-            if (L.mem[own][m] == idx) return true;
-        return false;
-    };
-    auto grid_entry = [&](int idx, const double4 &r) {
+    int q = amc_list_head(A.B, cell);
+    int h2 = skip_own(__hip_atomic_load(&W.ov_head[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // pre-sweep positions of the particles binned into the cell
+    while (q >= 0) {
+        const double4 r = A.B.rec[q];
+        const int idx = q;
+        q = amc_rec_next(r);
         const double ax = r.x - x, ay = r.y - y, az = r.z - z;
-        if (!(ax * ax + ay * ay + az * az < cr2i)) return;
-        if (member(idx)) return;
+        if (!(ax * ax + ay * ay + az * az < cr2i)) continue;
+        bool mine = false;
+        for (int m = 0; m < nm; m++) mine |= L.mem[own][m] == idx;
+        if (mine) continue;
         if (cw_adj_head(W, A.sweep_epoch, idx) < 0) {
             // in no candidate: pull it into this cluster, unless somebody else got it first
             const int tag = -(lab + 2);
             const int old = atomicCAS(&W.slot_of[idx], -1, tag);
-            if (old == tag) return;                             // another position of my cluster found it too
+            if (old == tag) continue;                           // another position of my cluster found it too
             if (old == -1) {
-                const int s = atomicAdd(&wc->nslots, 1);
+                const int s = h_off + atomicAdd(&wc->nslots, 1);
                 const int k = atomicAdd(&L.npull[own], 1);
                 if (s < W.max_slots && k < CW_PULLS) {
                     L.pull[own][k] = idx; L.psl[own][k] = s;   // (slot_of keeps the tag until the owner initialises the slot)
                     L.redo[own] = 1;
-                    return;
+                    continue;
                 }
                 if (s >= W.max_slots) wc->ovf = 1;
                 else { W.sl_meta[s] = make_int4(idx, s, 0, 0); W.sl_moved[s] = 0; atomicAnd(&W.sl_hits[s], 0); }
@@ -166,50 +145,22 @@ AMC_DEV void cw_probe(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item 
             }
         }
         rs_add_edge(W, wc, me.p, idx);
-    };
-    auto overlay_entry = [&](const double4 &o) {
-        const double ax = o.x - x, ay = o.y - y, az = o.z - z;
-        if (!(ax * ax + ay * ay + az * az < cr2i)) return;
-        const int s2 = rs_hist_slot(o);
-        for (int m = 0; m < nm; m++)
-            if (L.msl[own][m] == s2) return;
-        // position of an emulation that was redone since?  (its owner raised the slot's round before it published anew)
-        if (rs_hist_gen(o) != __hip_atomic_load(((int *)&W.sl_meta[s2]) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-        rs_add_edge(W, wc, me.p, -(s2 + 2));                    // (the other end as a slot)
-    };
-    // first element of every list before any is examined (the probe is a chain of dependent round trips)
-    double4 r0[8], o0[8];
-    int on0[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (lh[k] >= 0) r0[k] = A.B.rec[lh[k]];
-        ovh[k] = skip_own(ovh[k]);
-        if (ovh[k] >= 0) {
-            o0[k] = cw_load_hist(W, ovh[k]);
-            on0[k] = __hip_atomic_load(&W.ov_next[ovh[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (lh[k] >= 0) {
-            grid_entry(lh[k], r0[k]);
-            for (int q = amc_rec_next(r0[k]); q >= 0;) {
-                const double4 r = A.B.rec[q];
-                grid_entry(q, r);
-                q = amc_rec_next(r);
-            }
-        }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        if (ovh[k] >= 0) {
-            overlay_entry(o0[k]);
-            for (int h2 = skip_own(on0[k]); h2 >= 0;) {
-                const double4 o = cw_load_hist(W, h2);
-                const int nx = __hip_atomic_load(&W.ov_next[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                overlay_entry(o);
-                h2 = skip_own(nx);
-            }
-        }
+    // new positions of other clusters' members
+    while (h2 >= 0) {
+        const double4 o = cw_load_hist(W, h2);
+        const int nx = __hip_atomic_load(&W.ov_next[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h2 = skip_own(nx);
+        const double ax = o.x - x, ay = o.y - y, az = o.z - z;
+        if (!(ax * ax + ay * ay + az * az < cr2i)) continue;
+        const int s2 = rs_hist_slot(o);
+        bool mine = false;
+        for (int m = 0; m < nm; m++) mine |= L.msl[own][m] == s2;
+        if (mine) continue;
+        // position of an emulation that was redone since?  (its owner raised the slot's round before it published anew)
+        if (rs_hist_gen(o) != __hip_atomic_load(((int *)&W.sl_meta[s2]) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+        rs_add_edge(W, wc, me.p, -(s2 + 2));                    // (the other end as a slot)
+    }
 }
 
 template <int GEOM>
@@ -219,30 +170,37 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
     rs_shared *wc = (rs_shared *)W.wctl;
     __shared__ cw_lds L;
     const int lane = threadIdx.x;
+    const int nwaves = gridDim.x;
+    const int per = A.wide_per;         // candidates per wave and pass, fixed by the host: the first pass's candidate is
+                                        // known before the sweep's candidate count has arrived
+    // speculative: record and state of my first candidate (valid memory for any k below the capacity)
+    const int k_first = blockIdx.x * per + lane;
+    int4 c4_first = make_int4(0, 0, -1, -1);
+    if (lane < per && k_first < W.max_cand) c4_first = W.cand4[k_first];
     int ncand = (int)A.O.cnt->cand_count;
     if (ncand > W.max_cand) ncand = W.max_cand;
-    if (blockIdx.x == 0 && lane == 0) wc->active = 1;
+    if (blockIdx.x == 0 && lane == 0) { wc->active = 1; wc->ncand = ncand; }
     if (ncand == 0) return;
-    const int nwaves = gridDim.x;
-    int per = (ncand + nwaves - 1) / nwaves;
-    if (per > 64) per = 64;
+    const int h_off = 2 * ncand;        // first counter-allocated slot / history entry of this sweep
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_work K;
     K.x = L.pool_d[0]; K.y = L.pool_d[1]; K.z = L.pool_d[2]; K.vx = L.pool_d[3]; K.vy = L.pool_d[4]; K.vz = L.pool_d[5];
     K.d = L.pool_d[6]; K.dx = L.pool_d[7]; K.dy = L.pool_d[8]; K.dz = L.pool_d[9];
     K.tmp = L.pool_tmp; K.pidx = L.pool_pidx; K.slot = L.pool_slot; K.flag = L.pool_flag; K.moved = L.pool_moved;
 
+    // phase timers (diagnostic, AMC_DEBUG_RESOLVE=1): kept in registers and added to the debug buffer when the wave ends —
+    // an atomic per stamp would sit in the wave's memory queue in front of the loads it is supposed to time
     long long t_last = (A.dbg && lane == 0) ? wall_clock64() : 0;
+    long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0};
 #define CW_STAMP(slot)                                                                     \
     do {                                                                                   \
         if (timed__) {                                                                     \
             const long long now__ = wall_clock64();                                        \
-            atomicAdd((unsigned long long *)&A.dbg[16 + slot], (unsigned long long)(now__ - t_last));   \
+            t_acc[slot] += now__ - t_last;                                                 \
             t_last = now__;                                                                \
         }                                                                                  \
     } while (0)
     const bool timed__ = A.dbg && lane == 0 && blockIdx.x * per < ncand;     // waves with work in their first pass
-    if (timed__) atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
     for (int k0 = blockIdx.x * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
         const bool valid = lane < per && k < ncand;
@@ -251,7 +209,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         int4 c4 = make_int4(0, 0, -1, -1);
         int head_i = -1, head_j = -1;
         if (valid) {
-            c4 = W.cand4[k];
+            c4 = (k == k_first) ? c4_first : W.cand4[k];
             head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
             head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
         }
@@ -294,35 +252,34 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                 }
         }
         CW_STAMP(1);
-        // ---- 2. slots and history pairs for everything this wave owns ---------------------------------------------------
-        const int want_s = iso ? 2 : (owner ? nm : 0), want_h = iso ? 2 : (owner ? 2 * nc : 0);
-        int sbase, hbase;
-        cw_reserve2(&wc->nslots, want_s, &wc->nhist, want_h, sbase, hbase);
-        bool take = iso || owner;
-        if (take && (sbase + want_s > W.max_slots || hbase + want_h > W.max_hist)) { wc->ovf = 1; take = false; }
-        L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = sbase; L.npull[lane] = 0;
-        for (int m = 0; m < nm; m++) L.msl[lane][m] = sbase + m;
+        // ---- 2. no allocation: member t of a cluster takes slot 2 c + (t & 1) of the cluster's candidate c = cnd[t / 2]
+        // (a cluster of nc candidates has at most nc + 1 particles), the q-th hit the history pair of candidate cnd[q] ----
+        const bool take = iso || owner;
+        L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = 2 * k; L.npull[lane] = 0;
+        for (int m = 0; m < nm; m++) L.msl[lane][m] = 2 * cnd[m >> 1] + (m & 1);
         for (int r = 0; r < CW_ITERS; r++) { L.hb[lane][r] = 0; L.he[lane][r] = 0; L.it0[lane][r] = -1; }
-        L.hb[lane][0] = hbase; L.he[lane][0] = hbase + (take ? want_h : 0);
-        L.redo[lane] = (owner && take) ? 1 : 0;
+        L.redo[lane] = owner ? 1 : 0;
         L.gen[lane] = 0;
-        if (take)
-            for (int e = hbase; e < hbase + want_h; e++) W.ev_gen[e] = 0;       // "no event" until a hit stores one
         {
             const int ncl = __popcll(__ballot(take));
-            if (lane == 0 && ncl) atomicAdd(&wc->nclusters, ncl);
+            int ndone = iso ? 1 : (owner ? nc : 0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ndone += __shfl_xor(ndone, o, 64);
+            if (lane == 0 && ncl) { atomicAdd(&wc->nclusters, ncl); atomicAdd(&wc->changed, ndone); }
         }
         __syncthreads();
         CW_STAMP(2);
         // ---- 3a. isolated pairs: both particles in registers ------------------------------------------------------------------
-        if (iso && take) {
-            const int pj = c4.y, pi = c4.x, sj = sbase, si = sbase + 1;
+        if (iso) {
+            const int pj = c4.y, pi = c4.x, sj = 2 * k, si = 2 * k + 1;
             cw_init_slot(W, sj, pj, sj, 1);
             cw_init_slot(W, si, pi, sj, 1);
             W.cand_s[k] = make_int4(si, sj, 1, 0);
-            int pre_next = hbase, unval = 0;
+            int unval = 0;
+            L.used[lane] = 0;
             rs_wide wd;
-            wd.pre_next = &pre_next; wd.pre_end = hbase + 2; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+            wd.cnd = cnd; wd.ncnd = 1; wd.range_hb = 0; wd.range_he = 0; wd.used = &L.used[lane]; wd.h_off = h_off;
+            wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
             wd.own = lane; wd.gen = 1; wd.it0 = &L.it0[lane][0]; wd.unval = &unval;
             rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
             L.gen[lane] = 1;
@@ -339,7 +296,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                 todo &= todo - 1;
                 const int g = L.gen[src], ncs = L.nc[src], lab = L.lab[src];
                 if (lane == 0) {
-                    // particles the last validation pulled in become members; a new range of history pairs
+                    // particles the last validation pulled in become members; a re-emulation gets a range of history pairs
                     int m = L.nm[src];
                     const int np = L.npull[src] < CW_PULLS ? L.npull[src] : CW_PULLS;
                     L.unval = 0;
@@ -358,14 +315,14 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     L.nm[src] = m; L.npull[src] = 0;
                     if (g > 0) {
                         const int want = 2 * (ncs + m);
-                        const int hb = atomicAdd(&wc->nhist, want);
+                        const int hb = h_off + atomicAdd(&wc->nhist, want);
                         if (hb + want > W.max_hist) { wc->ovf = 1; L.hb[src][g] = 0; L.he[src][g] = 0; }
                         else {
                             L.hb[src][g] = hb; L.he[src][g] = hb + want;
                             for (int e = hb; e < hb + want; e++) W.ev_gen[e] = 0;
                         }
                     }
-                    L.hnext = L.hb[src][g];
+                    L.used[src] = 0;
                 }
                 __syncthreads();
                 const int m = L.nm[src];
@@ -387,7 +344,9 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     }
                 __syncthreads();
                 rs_wide wd;
-                wd.pre_next = &L.hnext; wd.pre_end = L.he[src][g]; wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+                wd.cnd = g == 0 ? L.cnd[src] : nullptr; wd.ncnd = ncs; wd.range_hb = L.hb[src][g]; wd.range_he = L.he[src][g];
+                wd.used = &L.used[src]; wd.h_off = h_off;
+                wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
                 wd.own = src; wd.gen = g + 1; wd.it0 = &L.it0[src][g]; wd.unval = &L.unval;
                 if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
                 else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
@@ -427,9 +386,19 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every push of this wave has returned
             __syncthreads();
             CW_STAMP(5);
-            for (int t0 = first_item; t0 < nit; t0 += 64) {
-                const int t = t0 + lane;
-                if (t < nit && !L.item[t].pad) cw_probe(A, wc, L, L.item[t], cr2i);
+            {
+                // the cells of a position's box go to different lanes while the wave has lanes to spare
+                const int nnew = nit - first_item;
+                const int lpi = nnew <= 8 ? 8 : (nnew <= 16 ? 4 : (nnew <= 32 ? 2 : 1));       // lanes per item
+                const int sub = lane % lpi;
+                for (int t = first_item + lane / lpi; t < nit; t += 64 / lpi) {
+                    const cw_item it = L.item[t];
+                    if (it.pad) continue;
+                    for (int c = sub; c < 8; c += lpi) {
+                        const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.P.collision_range * 1.000001, c);
+                        if (cell >= 0) cw_probe_cell(A, wc, L, it, cell, cr2i, h_off);
+                    }
+                }
             }
             first_item = nit;
             CW_STAMP(6);
@@ -447,12 +416,24 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         }
         __syncthreads();
     }
+    if (timed__) {
+        atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
+        for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[16 + e], (unsigned long long)t_acc[e]);
+    }
+}
+
+int amc_clusters_wide_blocks(amc_ctx *c)
+{
+    static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
+    if (nb_env > 0) return nb_env;
+    // one candidate per wave while the sweep is small; large sweeps get more waves rather than only more lanes per wave
+    const long long lag = c->h_host_ncand ? *c->h_host_ncand : 0;
+    return lag > 8 * CW_BLOCKS ? 4 * CW_BLOCKS : CW_BLOCKS;
 }
 
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
 {
-    static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
-    const int nb = nb_env > 0 ? nb_env : CW_BLOCKS;
+    const int nb = amc_clusters_wide_blocks(c);
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3(nb), dim3(64), 0, c->stream, A); break;
     default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3(nb), dim3(64), 0, c->stream, A); break;

@@ -46,6 +46,10 @@ struct amc_adj {
     unsigned long long *head;   // [n]   nullptr: the graph is not needed (all-pairs mode)
     int4 *rec;                  // [max_cand] (i, j, next in i's list, next in j's list)
     int4 *sd;                   // [max_cand] (slot of i, slot of j, done, -): reset here
+    // candidate k brings its own two slots (2k, 2k + 1) and its own pair of history / event entries (2k, 2k + 1): whoever
+    // emulates the candidate's cluster uses them without any allocation; here they are marked empty
+    int4 *sl_meta;
+    int *sl_hits, *ev_gen;
     unsigned int epoch;
 };
 
@@ -64,6 +68,14 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
         }
         D.rec[k] = r;
         D.sd[k] = make_int4(-1, -1, 0, 0);      // (slot of i, slot of j, done by the wide kernel, -)
+        if (D.head) {
+            D.sl_meta[2 * k] = make_int4(-1, 2 * (int)k, 0, 0);
+            D.sl_meta[2 * k + 1] = make_int4(-1, 2 * (int)k + 1, 0, 0);
+            atomicAnd(&D.sl_hits[2 * k], 0);    // (atomics, like the increments: no value needed back)
+            atomicAnd(&D.sl_hits[2 * k + 1], 0);
+            D.ev_gen[2 * k] = 0;
+            D.ev_gen[2 * k + 1] = 0;
+        }
         return (int)k;
     }
     atomicOr(&cnt->flags, 1ULL);
@@ -248,6 +260,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
     // workgroup itself, a large one by the wide commit kernel
     c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
     D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.sd = c->W.cand_s; D.epoch = c->sweep_epoch;
+    D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->allpairs) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);

@@ -58,6 +58,37 @@ AMC_DEV int amc_grid_box_ranges(const amc_grid &G, double x, double y, double z,
     return n;
 }
 
+// Cell number c (0..7) of the same enumeration: run c >> 1 (z-major, then y), end c & 1 (lower / upper x cell of the run);
+// -1 if there is none.  For probes that spread the cells of one box over several lanes.
+AMC_DEV int amc_grid_box_cell(const amc_grid &G, double x, double y, double z, double r, int c)
+{
+    const double ux = (x - G.x0) * G.inv_h, uy = (y - G.y0) * G.inv_h, uz = (z - G.z0) * G.inv_h;
+    const double fx0 = floor(ux), fy0 = floor(uy), fz0 = floor(uz);
+    const double t = r * G.inv_h + 1.0e-6;
+    const int cx = amc_clampi((int)fx0, 0, G.gx - 1), cy = amc_clampi((int)fy0, 0, G.gy - 1), cz = amc_clampi((int)fz0, 0, G.gz - 1);
+    const double fx = ux - fx0, fy = uy - fy0, fz = uz - fz0;
+    const bool ox = (fx0 < 0) || (fx0 > G.gx - 1), oy = (fy0 < 0) || (fy0 > G.gy - 1), oz = (fz0 < 0) || (fz0 > G.gz - 1);
+    const int x_lo = amc_clampi(cx - ((fx < t || ox) ? 1 : 0), 0, G.gx - 1), x_hi = amc_clampi(cx + ((fx > 1.0 - t || ox) ? 1 : 0), 0, G.gx - 1);
+    const int y_lo = amc_clampi(cy - ((fy < t || oy) ? 1 : 0), 0, G.gy - 1), y_hi = amc_clampi(cy + ((fy > 1.0 - t || oy) ? 1 : 0), 0, G.gy - 1);
+    const int z_lo = amc_clampi(cz - ((fz < t || oz) ? 1 : 0), 0, G.gz - 1), z_hi = amc_clampi(cz + ((fz > 1.0 - t || oz) ? 1 : 0), 0, G.gz - 1);
+    int run = c >> 1;
+    for (int kz = z_lo; kz <= z_hi; kz++) {
+        int lo = 0, nn = G.gx, off;
+        if (G.uniform) off = kz * G.gy * G.gx;
+        else { lo = G.lay_lo[kz]; nn = G.lay_n[kz]; off = G.lay_off[kz]; }
+        const int a = amc_clampi(x_lo - lo, 0, nn - 1), b = amc_clampi(x_hi - lo, 0, nn - 1);
+        const int ya = amc_clampi(y_lo - lo, 0, nn - 1), yb = amc_clampi(y_hi - lo, 0, nn - 1);
+        const int ny = yb - ya + 1;
+        if (run < ny) {
+            const int row = off + (ya + run) * nn;
+            if (c & 1) return b != a ? row + b : -1;
+            return row + a;
+        }
+        run -= ny;
+    }
+    return -1;
+}
+
 // ---- per-cell lists -----------------------------------------------------------------------------------------------------
 AMC_DEV int amc_rec_next(const double4 &r) { return (int)__double_as_longlong(r.w); }
 AMC_DEV double amc_rec_pack(int next) { return __longlong_as_double((long long)next); }

@@ -31,6 +31,8 @@
 // — the usual case — this kernel is the commit alone.  Without a detection grid (single cells, N <= 4096: MODE 2)
 // everything, brute-force validation included, happens here.
 #include <stdlib.h>
+#include <algorithm>
+
 #include "amc_resolve_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
@@ -77,14 +79,21 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         wide_ns = -1; wide_nh = 0; wide_dirty = 0; s_left = 0;
         sh.nslots = 0; sh.nhist = 0; sh.nev = 0; sh.nfp = 0; sh.ovf = 0; sh.nedges = 0; sh.nclusters = 0;
         if (MODE == 0 && A.wide_plan) {
+            // (candidate k owns slots 2k, 2k + 1 and the history pair (2k, 2k + 1); what the wide kernel took from its
+            // counters comes after those)
             rs_shared *wc = (rs_shared *)W.wctl;
-            sh.nslots = wc->nslots < W.max_slots ? wc->nslots : W.max_slots;
-            sh.nhist = wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges; sh.nclusters = wc->nclusters;
+            const int off = 2 * ncand;
+            sh.nslots = off + wc->nslots < W.max_slots ? off + wc->nslots : W.max_slots;
+            sh.nhist = off + wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges; sh.nclusters = wc->nclusters;
             wide_dirty = wc->dirty;
             wide_ns = wc->active ? sh.nslots : -1;              // (>= 0: the wide kernel ran, W.cand_s[k].z is valid)
             wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
+            s_left = ncand - wc->changed;                       // candidates it did not take (components too large for it)
             wc->nslots = 0; wc->nhist = 0; wc->nedges = 0; wc->nfp = 0; wc->ovf = 0; wc->dirty = 0; wc->nclusters = 0;
-            wc->active = 0; wc->cur_round = 1;
+            wc->changed = 0; wc->active = 0; wc->cur_round = 1;
+            if (wide_ns < 0) { sh.nslots = 0; sh.nhist = 0; s_left = ncand; }        // (it did not run)
+        } else {
+            s_left = ncand;
         }
         sh.nslots0 = 0;
         sh.dirty = 0; sh.changed = 0; sh.nhits = 0;
@@ -101,12 +110,6 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     const bool wide = wide_ns >= 0;
     const int gen_off = wide ? 16 : 0;          // (the wide kernel tags its own re-emulations of a cluster with rounds 1, 2, 3)
     const bool mono = (MODE == 2) || A.force_mono;      // commit in this kernel
-    {
-        int mine = 0;
-        for (int k = tid; k < ncand; k += RS_T) mine += !(wide && W.cand_s[k].z);
-        if (mine) atomicAdd(&s_left, mine);
-    }
-    __syncthreads();
     const int nleft = s_left;
     // nothing left and nothing found by the wide kernel's validation: the sweep is resolved, only the commit remains
     const bool resolved = wide && nleft == 0 && !wide_dirty;
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             W.edge_b[k] = eb < -1 ? -(eb + 2) : W.slot_of[eb];
         }
         edges_conv = nedges;
-        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.nclusters = 0; sh.ncomplex = 0; sh.cur_round = rounds + gen_off; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }
+        if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.ncomplex = 0; sh.cur_round = rounds + gen_off; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }
         __syncthreads();
         if (first) {
             // ---- connected components of what is left by label propagation (label = lowest slot id of the cluster) ---------------
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         // ---- members of clusters with 3+ particles are collected for the generic path ----------------------------------------
         unsigned long long *keys = lds_keys;
         for (int s = tid; s < ns; s += RS_T) {
-            if (V.label[s] == s) atomicAdd(&sh.nclusters, 1);
+            if (first && s >= wide_ns && V.label[s] == s) atomicAdd(&sh.nclusters, 1);     // (clusters made here; the wide kernel counted its own)
             if (V.size[V.label[s]] >= 3 && vdirty[V.label[s]]) {
                 const int k = atomicAdd(&sh.ncomplex, 1);
                 const unsigned long long key = ((unsigned long long)(unsigned)V.label[s] << 32) | (unsigned)W.sl_meta[s].x;
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     const bool defer = ok && A.defer_commit;        // the next streaming pass reads the slot arrays through slot_of[]
     for (int s = tid; s < ns && !defer; s += RS_T) {
         const int p = W.sl_meta[s].x;
+        if (p < 0) continue;                        // a candidate's slot that no particle took
         if (ok && W.sl_moved[s]) {
             rs_apply_slot(W, A.S, s, p);
         }
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         const int ns = ctl->lazy_ns < W.max_slots ? ctl->lazy_ns : W.max_slots;
         for (int s = gtid; s < ns; s += gstride) {
             const int p = W.sl_meta[s].x;
-            if (W.slot_of[p] != s) continue;            // consumed by a streaming pass already
+            if (p < 0 || W.slot_of[p] != s) continue;   // no particle in the slot / consumed by a streaming pass already
             if (W.sl_moved[s]) {
                 rs_apply_slot(W, A.S, s, p);
             }
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
     for (int s = gtid; s < ns; s += gstride) {
         const int p = W.sl_meta[s].x;
         if (ok && A.count_pp) { const int hs = W.sl_hits[s]; my_hits += hs & 0xffff; my_fp += hs >> 16; }
-        if (defer) continue;
+        if (defer || p < 0) continue;
         if (ok && W.sl_moved[s]) {
             rs_apply_slot(W, A.S, s, p);
         }
@@ -538,6 +542,13 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     rs_args Aw = A;
     Aw.wide_plan = 1;
     Aw.force_mono = c->plan_split ? 0 : 1;
+    {
+        // candidates per wave of the wide kernel from the lagging count (with head room; more candidates = more passes)
+        const long long lag = c->h_host_ncand ? *c->h_host_ncand : 0;
+        const long long nb = amc_clusters_wide_blocks(c);
+        long long per = (lag + lag / 4 + nb - 1) / nb;
+        Aw.wide_per = (int)std::min<long long>(std::max<long long>(per, 1), 64);
+    }
     amc_prof_cancel(c);                 // (the caller's bracket is re-opened below, around the kernel it is named after)
     amc_prof_begin(c, AMC_K_PAIRS_WIDE);
     amc_launch_clusters_wide(c, Aw);

@@ -30,6 +30,7 @@ struct rs_args {
     long long *dbg;           // optional [16] phase timers (wall_clock64 ticks, 100 MHz), diagnostic only
     unsigned int sweep_epoch; // tag of the W.adj_head entries that belong to this sweep
     int wide_plan;            // k_clusters_wide ran before this kernel: start from the counters it left in W.wctl
+    int wide_per;             // candidates per wave of k_clusters_wide (from the lagging candidate count)
 };
 
 // The argument block of the resolve kernels is 1.3 KB.  Read field by field from the kernarg segment it costs every wave a
@@ -48,6 +49,7 @@ struct rs_args {
 
 struct amc_ctx;
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A);      // amc_clusters.hip
+int amc_clusters_wide_blocks(amc_ctx *c);
 
 // counters of one sweep; lives in LDS while a resolve kernel runs and in W.ctl (global) between the kernels
 struct rs_shared {
@@ -133,14 +135,19 @@ struct cw_item {
     int h, own, p, pad;       // history entry, owner lane (its member list / slot range), particle
 };
 struct rs_wide {
-    int *pre_next;            // next reserved history pair of this lane / cluster
-    int pre_end;
+    // where the hit's pair of history entries comes from: the cluster's candidates bring one pair each (2c, 2c + 1, first
+    // emulation), a re-emulation has a contiguous range; beyond that the counter (then the ordered workgroup redoes it)
+    const int *cnd;           // candidates of the cluster (nullptr: use the range)
+    int ncnd;
+    int range_hb, range_he;
+    int *used;                // pairs taken so far
+    int h_off;                // first counter-allocated entry of this sweep (2 * ncand)
     cw_item *items;           // work items of the wave (LDS)
     int *nitems;
     int cap;
     int own;
     int gen;                  // round tag of this emulation (the wide kernel re-emulates a cluster that pulled a particle in)
-    int *it0;                 // where the owner's first work item went (-1: none yet)
+    int *it0;                 // where the owner's first work item of this emulation went (-1: none yet)
     int *unval;               // set when a hit got entries the wave cannot publish: the ordered workgroup redoes the cluster
 };
 
@@ -166,13 +173,14 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
 {
     const amc_resolve_ws &W = A.W;
     // the hit's pair of history entries (h: particle j, h + 1: particle i); its events use the same two indices
-    int h;
-    if (wd && *wd->pre_next + 2 <= wd->pre_end) {
-        h = *wd->pre_next;
-        *wd->pre_next = h + 2;
+    int h = -1;
+    if (wd) {
+        const int q = (*wd->used)++;
+        if (wd->cnd) { if (q < wd->ncnd) h = 2 * wd->cnd[q]; }
+        else if (wd->range_hb + 2 * q + 2 <= wd->range_he) h = wd->range_hb + 2 * q;
+        if (h < 0) { h = wd->h_off + rs_count_add(&sh->nhist, 2); *wd->unval = 1; }
     } else {
         h = rs_count_add(&sh->nhist, 2);
-        if (wd) *wd->unval = 1;
     }
     const bool room = h + 1 < W.max_hist;
     if (!room) sh->ovf = 1;
