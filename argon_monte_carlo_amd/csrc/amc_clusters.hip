@@ -80,7 +80,8 @@ struct cw_lds {
     int gen[64];                // emulations done
     cw_item item[CW_ITEMS];
     int next[CW_ITEMS];         // overlay `next` of every published item (own entries are stepped over without a load)
-    int nitems, unval;
+    int nitems;
+    int unv[64];                // the running emulation of the owner got entries the wave cannot publish
     double pool_d[10][CW_MAXM];
     int pool_tmp[CW_MAXM], pool_pidx[CW_MAXM], pool_slot[CW_MAXM];
     uint8_t pool_flag[CW_MAXM], pool_moved[CW_MAXM];
@@ -163,6 +164,60 @@ AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
     }
 }
 
+// Before an owner's cluster is emulated (again): the particles its last validation pulled in become members (kept in
+// ascending particle index, slots alongside), a re-emulation gets a contiguous range of history pairs from the counter.
+// Run by ONE lane per owner.  Returns the number of members.
+AMC_DEV int cw_prepare(const amc_resolve_ws &W, rs_shared *wc, cw_lds &L, int own, int h_off)
+{
+    int m = L.nm[own];
+    const int g = L.gen[own], lab = L.lab[own];
+    const int np = L.npull[own] < CW_PULLS ? L.npull[own] : CW_PULLS;
+    L.unv[own] = 0;
+    for (int e = 0; e < np; e++) {
+        const int v = L.pull[own][e], sv = L.psl[own][e];
+        if (m == CW_MAXM) {             // no room: it keeps its slot (same label) and the ordered workgroup takes over
+            cw_init_slot(W, sv, v, lab, 0);
+            L.unv[own] = 2;
+            continue;
+        }
+        int b = m - 1;
+        while (b >= 0 && L.mem[own][b] > v) { L.mem[own][b + 1] = L.mem[own][b]; L.msl[own][b + 1] = L.msl[own][b]; b--; }
+        L.mem[own][b + 1] = v; L.msl[own][b + 1] = sv;
+        m++;
+    }
+    L.nm[own] = m; L.npull[own] = 0;
+    if (g > 0) {
+        const int want = 2 * (L.nc[own] + m);
+        const int hb = h_off + atomicAdd(&wc->nhist, want);
+        if (hb + want > W.max_hist) { wc->ovf = 1; L.hb[own][g] = 0; L.he[own][g] = 0; }
+        else {
+            L.hb[own][g] = hb; L.he[own][g] = hb + want;
+            for (int e = hb; e < hb + want; e++) W.ev_gen[e] = 0;
+        }
+    }
+    L.used[own] = 0;
+    return m;
+}
+
+AMC_DEV void cw_wide_hooks(rs_wide &wd, cw_lds &L, int own, int h_off)
+{
+    const int g = L.gen[own];
+    wd.cnd = g == 0 ? L.cnd[own] : nullptr; wd.ncnd = L.nc[own]; wd.range_hb = L.hb[own][g]; wd.range_he = L.he[own][g];
+    wd.used = &L.used[own]; wd.h_off = h_off;
+    wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
+    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own][g]; wd.unval = &L.unv[own];
+}
+
+// slots of the cluster's candidates (first emulation only)
+AMC_DEV void cw_candidate_slots(const amc_resolve_ws &W, cw_lds &L, int own, int e)
+{
+    const int c = L.cnd[own][e], m = L.nm[own];
+    const int4 cc = W.cand4[c];
+    int ai = 0, aj = 0;
+    for (int t = 0; t < m; t++) { if (L.mem[own][t] == cc.x) ai = t; if (L.mem[own][t] == cc.y) aj = t; }
+    W.cand_s[c] = make_int4(L.msl[own][ai], L.msl[own][aj], 1, 0);
+}
+
 template <int GEOM>
 __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
 {
@@ -171,6 +226,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
     __shared__ cw_lds L;
     const int lane = threadIdx.x;
     const int nwaves = gridDim.x;
+    const long long t_enter__ = A.dbg ? wall_clock64() : 0;
     const int per = A.wide_per;         // candidates per wave and pass, fixed by the host: the first pass's candidate is
                                         // known before the sweep's candidate count has arrived
     // speculative: record and state of my first candidate (valid memory for any k below the capacity)
@@ -258,7 +314,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = 2 * k; L.npull[lane] = 0;
         for (int m = 0; m < nm; m++) L.msl[lane][m] = 2 * cnd[m >> 1] + (m & 1);
         for (int r = 0; r < CW_ITERS; r++) { L.hb[lane][r] = 0; L.he[lane][r] = 0; L.it0[lane][r] = -1; }
-        L.redo[lane] = owner ? 1 : 0;
+        L.redo[lane] = take ? 1 : 0;
         L.gen[lane] = 0;
         {
             const int ncl = __popcll(__ballot(take));
@@ -269,62 +325,55 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         }
         __syncthreads();
         CW_STAMP(2);
-        // ---- 3a. isolated pairs: both particles in registers ------------------------------------------------------------------
-        if (iso) {
-            const int pj = c4.y, pi = c4.x, sj = 2 * k, si = 2 * k + 1;
-            cw_init_slot(W, sj, pj, sj, 1);
-            cw_init_slot(W, si, pi, sj, 1);
-            W.cand_s[k] = make_int4(si, sj, 1, 0);
-            int unval = 0;
-            L.used[lane] = 0;
-            rs_wide wd;
-            wd.cnd = cnd; wd.ncnd = 1; wd.range_hb = 0; wd.range_he = 0; wd.used = &L.used[lane]; wd.h_off = h_off;
-            wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-            wd.own = lane; wd.gen = 1; wd.it0 = &L.it0[lane][0]; wd.unval = &unval;
-            rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
-            L.gen[lane] = 1;
-            if (unval) rs_add_edge(W, wc, pi, pi);          // (self edge: the ordered workgroup redoes this cluster)
-        }
-        CW_STAMP(3);
         int first_item = 0;
         for (int iter = 0; iter < CW_ITERS; iter++) {
-            // ---- 3b. clusters to be emulated (again), one after the other by the whole wave -------------------------------------
+            // ---- 3a. clusters of two or three particles: one lane each, everything in registers ----------------------------------
+            __syncthreads();
+            int my_m = 0;
+            if (L.redo[lane]) my_m = cw_prepare(W, wc, L, lane, h_off);
+            if (L.redo[lane] && my_m <= 3) {
+                const int g = L.gen[lane], lab = L.lab[lane];
+                rs_wide wd;
+                cw_wide_hooks(wd, L, lane, h_off);
+                if (my_m == 2) {
+                    // (an isolated pair; only ever emulated once: a pair that pulls a particle in comes back as three)
+                    const int pj = mem[0], pi = mem[1], sj = L.msl[lane][0], si = L.msl[lane][1];
+                    cw_init_slot(W, sj, pj, lab, g + 1);
+                    cw_init_slot(W, si, pi, lab, g + 1);
+                    W.cand_s[k] = make_int4(si, sj, 1, 0);
+                    rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
+                } else {
+                    amc_particle q[3];
+                    int pidx[3], slot[3];
+                    bool moved[3] = {false, false, false};
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        pidx[a] = mem[a]; slot[a] = L.msl[lane][a];
+                        q[a] = rs_load_particle(A.S, pidx[a]);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 3; a++) cw_init_slot(W, slot[a], pidx[a], lab, g + 1);
+                    if (g == 0)
+                        for (int e = 0; e < L.nc[lane]; e++) cw_candidate_slots(W, L, lane, e);
+                    rs_emulate_small<GEOM, 3>(A, wc, q, pidx, slot, moved, &wd);
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+                        if (moved[a]) rs_store_slot(W, slot[a], q[a]);
+                }
+                if (L.unv[lane]) rs_add_edge(W, wc, mem[0], mem[0]);     // (self edge: the ordered workgroup redoes this cluster)
+                L.gen[lane] = g + 1;
+                L.redo[lane] = 0;
+            }
+            // (a cluster whose pulled particle did not fit goes through the cooperative path below all the same: its members,
+            // the ones just pulled in too, get their slots there, and the self edge hands it to the ordered workgroup)
+            CW_STAMP(3);
+            // ---- 3b. larger clusters, one after the other by the whole wave (working set in LDS) ---------------------------------
             __syncthreads();
             unsigned long long todo = __ballot(L.redo[lane] != 0);
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const int g = L.gen[src], ncs = L.nc[src], lab = L.lab[src];
-                if (lane == 0) {
-                    // particles the last validation pulled in become members; a re-emulation gets a range of history pairs
-                    int m = L.nm[src];
-                    const int np = L.npull[src] < CW_PULLS ? L.npull[src] : CW_PULLS;
-                    L.unval = 0;
-                    for (int e = 0; e < np; e++) {
-                        const int v = L.pull[src][e], sv = L.psl[src][e];
-                        if (m == CW_MAXM) {             // no room: it keeps its slot (same label) and the ordered workgroup takes over
-                            cw_init_slot(W, sv, v, lab, 0);
-                            L.unval = 2;
-                            continue;
-                        }
-                        int b = m - 1;
-                        while (b >= 0 && L.mem[src][b] > v) { L.mem[src][b + 1] = L.mem[src][b]; L.msl[src][b + 1] = L.msl[src][b]; b--; }
-                        L.mem[src][b + 1] = v; L.msl[src][b + 1] = sv;
-                        m++;
-                    }
-                    L.nm[src] = m; L.npull[src] = 0;
-                    if (g > 0) {
-                        const int want = 2 * (ncs + m);
-                        const int hb = h_off + atomicAdd(&wc->nhist, want);
-                        if (hb + want > W.max_hist) { wc->ovf = 1; L.hb[src][g] = 0; L.he[src][g] = 0; }
-                        else {
-                            L.hb[src][g] = hb; L.he[src][g] = hb + want;
-                            for (int e = hb; e < hb + want; e++) W.ev_gen[e] = 0;
-                        }
-                    }
-                    L.used[src] = 0;
-                }
-                __syncthreads();
                 const int m = L.nm[src];
                 if (lane < m) {
                     const int p = L.mem[src][lane], sl = L.msl[src][lane];
@@ -334,26 +383,16 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     cw_init_slot(W, sl, p, lab, g + 1);
                 }
                 if (g == 0)
-                    for (int e = lane; e < ncs; e += 64) {
-                        const int c = L.cnd[src][e];
-                        const int4 cc = W.cand4[c];
-                        const int pi = cc.x, pj = cc.y;
-                        int ai = 0, aj = 0;
-                        for (int t = 0; t < m; t++) { if (L.mem[src][t] == pi) ai = t; if (L.mem[src][t] == pj) aj = t; }
-                        W.cand_s[c] = make_int4(L.msl[src][ai], L.msl[src][aj], 1, 0);
-                    }
+                    for (int e = lane; e < ncs; e += 64) cw_candidate_slots(W, L, src, e);
                 __syncthreads();
                 rs_wide wd;
-                wd.cnd = g == 0 ? L.cnd[src] : nullptr; wd.ncnd = ncs; wd.range_hb = L.hb[src][g]; wd.range_he = L.he[src][g];
-                wd.used = &L.used[src]; wd.h_off = h_off;
-                wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-                wd.own = src; wd.gen = g + 1; wd.it0 = &L.it0[src][g]; wd.unval = &L.unval;
+                cw_wide_hooks(wd, L, src, h_off);
                 if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
                 else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
                 __syncthreads();
                 if (lane < m && K.moved[lane]) rs_store_slot(W, K.slot[lane], rs_load_work(K, lane));
                 if (lane == 0) {
-                    if (L.unval) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);     // (self edge: the ordered workgroup redoes it)
+                    if (L.unv[src]) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);  // (self edge: the ordered workgroup redoes it)
                     L.gen[src] = g + 1;
                     L.redo[src] = 0;
                 }
@@ -416,7 +455,12 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         }
         __syncthreads();
     }
+    if (A.dbg && lane == 0) {       // span of the launch as the device sees it: first wave in, last wave out
+        atomicMin((unsigned long long *)&A.dbg[28], (unsigned long long)t_enter__);
+        atomicMax((unsigned long long *)&A.dbg[29], (unsigned long long)wall_clock64());
+    }
     if (timed__) {
+        atomicMax((unsigned long long *)&A.dbg[30], (unsigned long long)(wall_clock64() - t_enter__));
         atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
         for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[16 + e], (unsigned long long)t_acc[e]);
     }

@@ -54,6 +54,9 @@ template <int GEOM, int MODE>
 __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
+    if (A.dbg && threadIdx.x == 0 && MODE == 0 && A.dbg[29] > 0) {      // span of the wide kernel's launch (first wave in -> last wave out)
+        A.dbg[27] += A.dbg[29] - A.dbg[28]; A.dbg[26] += t_last - A.dbg[29]; A.dbg[28] = 0x7fffffffffffffffLL; A.dbg[29] = 0;
+    }
     __shared__ rs_shared sh;
     __shared__ int wide_ns;             // slots made by the wide cluster kernel in this sweep, -1 if it did not run
     __shared__ int wide_nh;             // history entries it made (published and validated there)
@@ -169,8 +172,10 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         }
         for (int k = edges_conv + tid; k < nedges; k += RS_T) {
             const int ea = W.edge_a[k], eb = W.edge_b[k];
-            W.edge_a[k] = ea < -1 ? -(ea + 2) : W.slot_of[ea];
-            W.edge_b[k] = eb < -1 ? -(eb + 2) : W.slot_of[eb];
+            const int sa = ea < -1 ? -(ea + 2) : W.slot_of[ea], sb = eb < -1 ? -(eb + 2) : W.slot_of[eb];
+            W.edge_a[k] = sa;
+            W.edge_b[k] = sb;
+            if (sa < 0 || sb < 0) sh.ovf = 1;       // (an end without a slot cannot happen; fail the step rather than merge nothing forever)
         }
         edges_conv = nedges;
         if (tid == 0) { s_nheads = 0; sh.dirty = 0; sh.ncomplex = 0; sh.cur_round = rounds + gen_off; sh.hist_begin = first ? wide_nh : (sh.nhist < W.max_hist ? sh.nhist : W.max_hist); }

@@ -323,14 +323,19 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int
         // The stale masks come out of the structure: the x test is made once when an x-layer starts, the y test
         // once per (x,y)-layer, the z test per cell, each from the state at that moment (in_x_layer / in_y_layer /
         // in_z_layer); none is re-evaluated after a hit inside the layer.
-        for (int lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, 0); lx >= 0;
-             lx = rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1))
+        // (the overlap test depends on the positions only: it is re-evaluated after a hit, and once the pair no longer
+        // overlaps no later cell can do anything — the remaining layers are not enumerated)
+        bool ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);
+        for (int lx = ov ? rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, 0) : -1; lx >= 0;
+             lx = ov ? rs_next_common(p1.x, p2.x, P.dx, A.inv_dx, P.overlap_x, P.nx, lx + 1) : -1)
             for (int ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, 0); ly >= 0;
-                 ly = rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1))
+                 ly = ov ? rs_next_common(p1.y, p2.y, P.dy, A.inv_dy, P.overlap_y, P.ny, ly + 1) : -1)
                 for (int lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, 0); lz >= 0;
-                     lz = rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1))
-                    if (amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr))
+                     lz = ov ? rs_next_common(p1.z, p2.z, P.dz, A.inv_dz, P.overlap_z, P.nz, lz + 1) : -1)
+                    if (ov) {
                         moved |= rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16, ((long long)lx * P.ny + ly) * P.nz + lz, wd);
+                        ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);
+                    }
     } else {
         // Pore:522-530.  Along one axis a coordinate belongs to at most two overlapping cells k (one of each parity);
         // they are found once per particle (rs_axis_k) and re-derived only after a hit moved the particles, instead of
@@ -363,6 +368,130 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int
     if (moved) {
         rs_store_slot(A.W, sj, p1);
         rs_store_slot(A.W, si, p2);
+    }
+}
+
+// ---- small cluster (M = 3 or 4 members), all members in registers of ONE lane ----------------------------------------
+// The same literal emulation as rs_emulate_generic below, with the member loops unrolled so that every member index is a
+// compile-time constant (no LDS working set, no wave-level synchronisation): members in ascending particle index,
+// pairs (c, a) with c < a in the order a = 1.., c = 0..a-1 (Pore:168-169), membership masks taken at the moments the
+// reference takes them (Cube:233-238 stale in_x / in_y / in_z; Pore:527-530 at the gather of a colour group).
+// What keeps it short: the overlap test of a pair depends on the positions only, so it is evaluated once per pair and
+// again only for the pairs of a particle that a hit has moved; layers and colour groups are searched for OVERLAPPING
+// pairs only (a cell in which no pair overlaps does nothing), and when no pair overlaps any more the rest of the sweep
+// cannot do anything.
+template <int M>
+AMC_DEV int rs_small_next_layer(const double (&v)[M], const bool (&ok)[M], const bool (&ovp)[M][M], double d, double inv_d,
+                                double ov, int n, int from)
+{
+    int best = -1;
+#pragma unroll
+    for (int a = 1; a < M; a++)
+#pragma unroll
+        for (int c = 0; c < a; c++) {
+            if (!ovp[c][a] || !ok[a] || !ok[c]) continue;
+            const int l = rs_next_common(v[a], v[c], d, inv_d, ov, n, from);
+            if (l >= 0 && (best < 0 || l < best)) best = l;
+        }
+    return best;
+}
+
+template <int GEOM, int M>
+AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)[M], const int (&pidx)[M],
+                              const int (&slot)[M], bool (&moved)[M], rs_wide *wd)
+{
+    const amc_params &P = A.P;
+    const double cr = P.collision_range;
+    bool ovp[M][M];                     // ovp[c][a], c < a: the pair overlaps at the current positions
+    bool any = false;
+#pragma unroll
+    for (int a = 1; a < M; a++)
+#pragma unroll
+        for (int c = 0; c < a; c++) {
+            ovp[c][a] = amc_overlap(q[c].x, q[c].y, q[c].z, q[a].x, q[a].y, q[a].z, cr);
+            any |= ovp[c][a];
+        }
+    // a hit on (c0, a0): collide, then re-evaluate the pairs that contain one of the two
+    auto hit = [&](int c0, int a0, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj, int si, int phase, long long cell) {
+        if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, phase, cell, wd)) { moved[c0] = true; moved[a0] = true; }
+        any = false;
+#pragma unroll
+        for (int a = 1; a < M; a++)
+#pragma unroll
+            for (int c = 0; c < a; c++) {
+                if (c == c0 || c == a0 || a == c0 || a == a0)
+                    ovp[c][a] = amc_overlap(q[c].x, q[c].y, q[c].z, q[a].x, q[a].y, q[a].z, cr);
+                any |= ovp[c][a];
+            }
+    };
+    if (GEOM == AMC_GEOM_CELL) {
+#pragma unroll
+        for (int a = 1; a < M; a++)
+#pragma unroll
+            for (int c = 0; c < a; c++)
+                if (ovp[c][a]) hit(c, a, q[c], q[a], pidx[c], pidx[a], slot[c], slot[a], 16, 0);
+    } else if (GEOM == AMC_GEOM_CUBE) {
+        bool all[M], in_x[M], in_y[M], in_z[M];
+        double v[M];
+#pragma unroll
+        for (int a = 0; a < M; a++) all[a] = true;
+        for (int lx = 0; any;) {
+#pragma unroll
+            for (int a = 0; a < M; a++) v[a] = q[a].x;
+            lx = rs_small_next_layer<M>(v, all, ovp, P.dx, A.inv_dx, P.overlap_x, P.nx, lx);
+            if (lx < 0) break;
+            const double xlo = lx * P.dx - P.overlap_x, xhi = (lx + 1) * P.dx;              // Cube:233
+#pragma unroll
+            for (int a = 0; a < M; a++) in_x[a] = (xlo < q[a].x) && (q[a].x < xhi);
+            for (int ly = 0; any;) {
+#pragma unroll
+                for (int a = 0; a < M; a++) v[a] = q[a].y;
+                ly = rs_small_next_layer<M>(v, in_x, ovp, P.dy, A.inv_dy, P.overlap_y, P.ny, ly);
+                if (ly < 0) break;
+                const double ylo = ly * P.dy - P.overlap_y, yhi = (ly + 1) * P.dy;          // Cube:235
+#pragma unroll
+                for (int a = 0; a < M; a++) in_y[a] = in_x[a] && (ylo < q[a].y) && (q[a].y < yhi);
+                for (int lz = 0; any;) {
+#pragma unroll
+                    for (int a = 0; a < M; a++) v[a] = q[a].z;
+                    lz = rs_small_next_layer<M>(v, in_y, ovp, P.dz, A.inv_dz, P.overlap_z, P.nz, lz);
+                    if (lz < 0) break;
+                    const double zlo = lz * P.dz - P.overlap_z, zhi = (lz + 1) * P.dz;      // Cube:237
+#pragma unroll
+                    for (int a = 0; a < M; a++) in_z[a] = in_y[a] && (zlo < q[a].z) && (q[a].z < zhi);
+                    const long long cell = ((long long)lx * P.ny + ly) * P.nz + lz;
+#pragma unroll
+                    for (int a = 1; a < M; a++)
+#pragma unroll
+                        for (int c = 0; c < a; c++)
+                            if (in_z[a] && in_z[c] && ovp[c][a])
+                                hit(c, a, q[c], q[a], pidx[c], pidx[a], slot[c], slot[a], 16, cell);
+                    lz++;
+                }
+                ly++;
+            }
+            lx++;
+        }
+    } else {
+        // Pore:522-530: the (at most two) cells k of every coordinate are found once per member (rs_axis_k) and again only
+        // after a hit moved it; membership of a colour group's cell is decided at the gather of the group
+        int ks[M][6];
+#pragma unroll
+        for (int a = 0; a < M; a++) rs_pore_ks(A, q[a], ks[a]);
+        for (int g = 0; g < 8 && any; g++) {                                                 // Pore:522-524
+            int cell[M];
+#pragma unroll
+            for (int a = 0; a < M; a++) cell[a] = rs_pore_cell_k(P, ks[a], g);              // membership at gather time
+#pragma unroll
+            for (int a = 1; a < M; a++)
+#pragma unroll
+                for (int c = 0; c < a; c++)
+                    if (ovp[c][a] && cell[a] >= 0 && cell[c] == cell[a]) {
+                        hit(c, a, q[c], q[a], pidx[c], pidx[a], slot[c], slot[a], 16 + g, cell[a]);
+                        rs_pore_ks(A, q[c], ks[c]);
+                        rs_pore_ks(A, q[a], ks[a]);
+                    }
+        }
     }
 }
 
