@@ -470,9 +470,7 @@ int amc_clusters_wide_blocks(amc_ctx *c)
 {
     static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
     if (nb_env > 0) return nb_env;
-    // one candidate per wave while the sweep is small; large sweeps get more waves rather than only more lanes per wave
-    const long long lag = c->h_host_ncand ? *c->h_host_ncand : 0;
-    return lag > 8 * CW_BLOCKS ? 4 * CW_BLOCKS : CW_BLOCKS;
+    return CW_BLOCKS;
 }
 
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
