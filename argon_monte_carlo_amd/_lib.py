@@ -80,7 +80,45 @@ def build(verbose=False):
         print(r.stdout.decode(errors="replace")[-4000:])
     if r.returncode != 0:
         raise RuntimeError("building libargonmc.so failed")
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(source_digest() + "\n")
     return LIB_PATH
+
+
+STAMP_PATH = LIB_PATH + ".sources"
+
+
+def _source_files():
+    src_dir = os.path.join(_HERE, "csrc")
+    files = [os.path.join(src_dir, f) for f in sorted(os.listdir(src_dir)) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "argonmc.h"))
+    return files
+
+
+def source_digest():
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, the Makefile, include/argonmc.h)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _source_files():
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stale_sources():
+    """Non-empty when the built libargonmc.so does not belong to the sources in the tree.  The .so is not under version
+    control (it travels with the working tree, and file times do not survive every copy): build() leaves the digest of
+    the sources it compiled next to it, and a library without a matching digest is refused — it would silently run old
+    kernels."""
+    if not os.path.exists(LIB_PATH):
+        return []
+    try:
+        with open(STAMP_PATH) as fh:
+            built = fh.read().strip()
+    except OSError:
+        return ["(no source digest next to the library)"]
+    return [] if built == source_digest() else ["(sources changed since the library was built)"]
 
 
 def load():
@@ -91,6 +129,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ArgonMCError(-2, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(no CPU fallback exists)")
+    stale = stale_sources()
+    if stale:
+        raise ArgonMCError(-3, f"{LIB_PATH} does not match the sources {stale[0]}: rebuild it "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`)")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError = missing export

@@ -161,12 +161,13 @@ void amc_destroy(amc_ctx *c)
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
                     c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.ov_head, c->w_slab, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->d_banks, c->d_dbg, c->T.idx, c->T.count, c->T.t, c->T.contact,
-                    c->T.normal, c->T.dir, c->T.Es, c->T.dpz, c->T.dE, c->T.ok};
+                    c->d_edges, c->d_cnt, c->d_banks, c->d_dbg};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
     if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->T.pin) hipHostFree(c->T.pin);
+    if (c->T.count) hipFree(c->T.count);
     { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
       for (void *q : td) if (q) hipFree(q); }
     if (c->kin_send) hipFree(c->kin_send);
@@ -208,7 +209,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
-    c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0;
+    c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pin = nullptr;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr; c->w_slab = nullptr;

@@ -12,9 +12,26 @@ static int temp_ensure(amc_ctx *c)
     amc_temp_ws &T = c->T;
     T.cap = (int)std::min<int64_t>(std::max<int64_t>(4096, c->n / 8 + 1024), 0x3fffffff);
     const size_t cap = (size_t)T.cap;
-    AMC_HIP(c, dalloc(&T.idx, cap)); AMC_HIP(c, dalloc(&T.count, 1)); AMC_HIP(c, dalloc(&T.t, cap));
-    AMC_HIP(c, dalloc(&T.contact, 3 * cap)); AMC_HIP(c, dalloc(&T.normal, 3 * cap)); AMC_HIP(c, dalloc(&T.dir, 3 * cap));
-    AMC_HIP(c, dalloc(&T.Es, cap)); AMC_HIP(c, dalloc(&T.dpz, cap)); AMC_HIP(c, dalloc(&T.dE, cap)); AMC_HIP(c, dalloc(&T.ok, cap));
+    // one pinned, device-mapped block: [count | idx | t | contact | normal | dir | Es | dpz | dE | ok]
+    size_t off = 0;
+    auto place = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_count = place(64), o_idx = place(sizeof(int) * cap), o_t = place(sizeof(double) * cap),
+                 o_contact = place(sizeof(double) * 3 * cap), o_normal = place(sizeof(double) * 3 * cap),
+                 o_dir = place(sizeof(double) * 3 * cap), o_Es = place(sizeof(double) * cap), o_dpz = place(sizeof(double) * cap),
+                 o_dE = place(sizeof(double) * cap), o_ok = place(cap);
+    void *hp = nullptr, *dp = nullptr;
+    AMC_HIP(c, hipHostMalloc(&hp, off, hipHostMallocMapped));
+    if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { hipHostFree(hp); return amc_fail(c, AMC_ERR_HIP, "hipHostGetDevicePointer failed"); }
+    memset(hp, 0, off);
+    T.pin = hp;
+    char *h = (char *)hp, *d = (char *)dp;
+    AMC_HIP(c, dalloc(&T.count, 16));       // (the hit counter stays in device memory: every hit increments it atomically)
+    T.idx = (int *)(d + o_idx); T.t = (double *)(d + o_t); T.contact = (double *)(d + o_contact);
+    T.normal = (double *)(d + o_normal); T.dir = (double *)(d + o_dir); T.Es = (double *)(d + o_Es); T.dpz = (double *)(d + o_dpz);
+    T.dE = (double *)(d + o_dE); T.ok = (unsigned char *)(d + o_ok);
+    T.h_count = (int *)(h + o_count); T.h_idx = (int *)(h + o_idx); T.h_contact = (double *)(h + o_contact);
+    T.h_normal = (double *)(h + o_normal); T.h_dir = (double *)(h + o_dir); T.h_Es = (double *)(h + o_Es);
+    T.h_dpz = (double *)(h + o_dpz); T.h_dE = (double *)(h + o_dE);
     T.last_case = -1; T.last_n = 0;
     return AMC_OK;
 }
@@ -39,22 +56,17 @@ int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, dou
     if (rc) return rc;
     amc_temp_ws &T = c->T;
     AMC_HIP(c, amc_launch_temp_hits(c, case_id));
-    int cnt = 0;
-    amc_stage stg(c);
-    AMC_HIP(c, stg.get(&cnt, T.count, sizeof cnt));
-    AMC_HIP(c, stg.finish());
+    AMC_HIP(c, hipMemcpyAsync(T.h_count, T.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));        // the records are in host memory now (the kernel wrote them there)
+    const int cnt = *T.h_count;
     if (cnt > T.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits exceed the record capacity %d", cnt, T.cap);
     if ((size_t)cnt > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits, caller buffer holds %zu", cnt, cap);
     T.last_case = case_id; T.last_n = cnt;
     T.perm.resize((size_t)cnt);
     *n = (size_t)cnt;
     if (cnt == 0) return AMC_OK;
-    std::vector<int> hidx((size_t)cnt);
-    std::vector<double> hnorm(3 * (size_t)cnt), hcontact(3 * (size_t)cnt);
-    AMC_HIP(c, stg.get(hidx.data(), T.idx, sizeof(int) * cnt));
-    AMC_HIP(c, stg.get(hnorm.data(), T.normal, sizeof(double) * 3 * cnt));
-    AMC_HIP(c, stg.get(hcontact.data(), T.contact, sizeof(double) * 3 * cnt));
-    AMC_HIP(c, stg.finish());
+    const int *hidx = T.h_idx;
+    const double *hnorm = T.h_normal, *hcontact = T.h_contact;
     for (int k = 0; k < cnt; k++) T.perm[k] = k;
     std::sort(T.perm.begin(), T.perm.end(), [&](int a, int b) { return hidx[a] < hidx[b]; });   // ascending particle index
     for (int s = 0; s < cnt; s++) {
@@ -76,24 +88,17 @@ int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double 
     T.last_case = -1;
     if (n == 0) return AMC_OK;
     if (!dir_xyz || !surface_energy) return AMC_ERR_INVALID;
-    // caller order (ascending particle index) -> record order
-    std::vector<double> hdir(3 * n), hEs(n);
+    // caller order (ascending particle index) -> record order, written where the kernel reads it
     for (size_t s = 0; s < n; s++) {
         const int k = T.perm[s];
-        hdir[3 * k] = dir_xyz[3 * s]; hdir[3 * k + 1] = dir_xyz[3 * s + 1]; hdir[3 * k + 2] = dir_xyz[3 * s + 2];
-        hEs[k] = surface_energy[s];
+        T.h_dir[3 * k] = dir_xyz[3 * s]; T.h_dir[3 * k + 1] = dir_xyz[3 * s + 1]; T.h_dir[3 * k + 2] = dir_xyz[3 * s + 2];
+        T.h_Es[k] = surface_energy[s];
     }
-    AMC_HIP(c, hipMemcpyAsync(T.dir, hdir.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
-    AMC_HIP(c, hipMemcpyAsync(T.Es, hEs.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n));
-    std::vector<double> hp(n), he(n);
-    amc_stage stg(c);
-    AMC_HIP(c, stg.get(hp.data(), T.dpz, sizeof(double) * n));
-    AMC_HIP(c, stg.get(he.data(), T.dE, sizeof(double) * n));
-    AMC_HIP(c, stg.finish());
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
     for (size_t s = 0; s < n; s++) {
-        if (dpz) dpz[s] = hp[T.perm[s]];
-        if (dE) dE[s] = he[T.perm[s]];
+        if (dpz) dpz[s] = T.h_dpz[T.perm[s]];
+        if (dE) dE[s] = T.h_dE[T.perm[s]];
     }
     return AMC_OK;
 }

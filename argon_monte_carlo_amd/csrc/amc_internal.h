@@ -97,9 +97,15 @@ struct amc_resolve_ws {
 
 // energised-wall hand-over buffers (amc_energised.hip)
 struct amc_temp_ws {
+    // The records live in ONE block of pinned host memory mapped into the device: the kernels write the (few hundred) hits of
+    // a case straight into it and read the host's directions / energies from it — the hand-over of a case is two kernel
+    // launches and two stream synchronisations, no copies.  Device addresses first, the host's view of the same bytes after.
     int *idx, *count;
     double *t, *contact, *normal, *dir, *Es, *dpz, *dE;
     unsigned char *ok;
+    int *h_idx, *h_count;
+    double *h_contact, *h_normal, *h_dir, *h_Es, *h_dpz, *h_dE;
+    void *pin;
     int cap;
     int last_case, last_n;       // the pending amc_wall_hits
     std::vector<int> perm;       // sorted position -> record slot of the pending hits

@@ -5,9 +5,11 @@
 
 A "step" is one full timestep(dt) over all particles (BASELINE.json metric: particle-steps/sec + achieved HBM GB/s).
 At N=1 the default workload is BASELINE configs[1]: Open_Air_Cube_MC geometry, N = 100,000 synthetic uniform-cube
-argon.  State is resident in HBM before the timed region starts.  For N>1 the driver launches
-one rank per GPU through torch.distributed.run; particles are sharded by index range with a per-step all-gather of
-positions (argon_monte_carlo_amd/dist.py) and per-GPU work is fixed (weak scaling).
+argon.  State is resident in HBM before the timed region starts.  For N>1 one rank runs per GPU
+over RCCL: either the caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`:
+RANK / WORLD_SIZE are in the environment) or `python bench.py --gpus N` starts them itself — as child processes of a
+parent that has not touched the GPU — and relays rank 0's JSON line.  Particles are sharded by index range with a
+per-step all-gather of positions (argon_monte_carlo_amd/dist.py) and per-GPU work is fixed (weak scaling).
 
 Prints ONE JSON line on rank 0 with the contract keys plus `roofline` (dominant kernel, HIP-event timed on the
 launch stream) and `cpu_baseline` (the C oracle = single-thread port of the reference algorithm, bounded sample).
@@ -108,6 +110,29 @@ def committed_traffic(workload, kclass, tag):
     return None, None
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a CHILD
+    process — this parent has made no HIP / torch.cuda call, and it never replaces itself with another program — and pass
+    rank 0's JSON line through.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round-tag", default="r01", help="prefix of the committed profile files to take `traffic` from")
@@ -124,6 +149,10 @@ def main():
                     help="temp workloads: opt-in NON-PARITY mode, re-emission directions / gap energies drawn on the GPU (Philox)")
     ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
     # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner at communicator
     # creation) are sent to stderr for the duration of the run
     sys.stdout.flush()

@@ -390,20 +390,20 @@ def test_pore_5e5_properties(Engine):
     tot = eng.run(c["dt"], 19)
     before = eng.download()
     # the sweep alone (stage call) on the current state
-    eng.stage_drift(c["dt"]); eng.stage_walls(); eng.stage_bounds()
+    eng.stage_drift(c["dt"]); sw = eng.stage_walls(); eng.stage_bounds()
     pre = eng.download()
     st = eng.stage_sweep()
     post = eng.download()
     assert st["n_pp"] > 50
     np.testing.assert_allclose(conserved(post), conserved(pre), rtol=1e-12)
     moved = np.flatnonzero((post["x"] != pre["x"]) | (post["y"] != pre["y"]) | (post["z"] != pre["z"]))
-    assert len(moved) == 2 * st["n_pp"] or len(moved) <= 2 * st["n_pp"]          # chains touch a particle twice
+    assert st["n_pp"] < len(moved) <= 2 * st["n_pp"]                                # (a chain touches a particle twice)
     eng.stage_bounds()
     fin = eng.download()
     r2 = fin["x"] ** 2 + fin["y"] ** 2
     assert np.all(fin["z"] >= 0) and np.all(fin["z"] <= p.H) and np.all(r2 <= p.R_oa_sq * (1 + 1e-12))
     counts, npaths = eng.histograms()
-    assert npaths == tot["n_paths"] + st["n_paths"] + 0 or npaths >= tot["n_paths"]
+    assert npaths == tot["n_paths"] + sw["n_paths"] + st["n_paths"]                  # run + the wall stage + the sweep stage
     assert counts.sum(axis=1).max() <= npaths
     eng.close()
 

@@ -24,6 +24,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.amc_abi_version() == AMC_ABI_VERSION == 2
 
 
+def test_a_library_that_does_not_match_the_sources_is_refused(monkeypatch):
+    """libargonmc.so travels with the working tree, not with git: the loader compares the digest build() left next to
+    it with the sources in the tree and refuses a stale library instead of silently running old kernels."""
+    assert _lib.stale_sources() == []
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "source_digest", lambda: "0" * 64)
+    with pytest.raises(_lib.ArgonMCError) as ei:
+        _lib.load()
+    assert ei.value.code == -3 and "rebuild" in str(ei.value)
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
