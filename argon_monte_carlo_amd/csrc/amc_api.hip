@@ -150,7 +150,7 @@ const char *amc_last_error(const amc_ctx *ctx) { return ctx ? ctx->err.c_str() :
 const char *amc_kernel_name(int k)
 {
     static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan",     "bin_scatter", "detect",  "resolve",
-                                             "bounds",      "validate",  "resolve_more", "commit",      "pairs_wide", "other11"};
+                                             "bounds",      "validate",  "resolve_more", "commit",      "clusters_wide", "other11"};
     return (k >= 0 && k < AMC_K_COUNT) ? names[k] : "?";
 }
 
@@ -238,7 +238,10 @@ int amc_create(amc_ctx **out, const amc_params *p)
         c->stream = c->own_stream;
         const size_t n = (size_t)c->n;
         // detection mode: single cells and small N use the LDS-tiled all-pairs kernel
-        c->allpairs = (p->geometry == AMC_GEOM_CELL) || p->detect_mode == 2 || (p->detect_mode == 0 && c->n <= 4096);
+        // (detect_mode 2 above 4096 particles: the all-pairs DETECTOR in front of the grid-based resolve — the kernel the
+        // reference's pairwise loop maps to directly, measurable at full size against the fp64 vector peak)
+        c->allpairs = (p->geometry == AMC_GEOM_CELL) || (p->detect_mode != 1 && c->n <= 4096);
+        c->detect_ap = c->allpairs || p->detect_mode == 2;
         if (p->geometry == AMC_GEOM_CELL && p->detect_mode == 1) {
             rc = amc_fail(c, AMC_ERR_INVALID, "AMC_GEOM_CELL has no cell grid: detect_mode must be 0 or 2");
             goto fail;

@@ -222,9 +222,13 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
     int jmax = n - j0;
     if (jmax > AP_T) jmax = AP_T;
     if (bi == bj && jmax > (int)threadIdx.x) jmax = threadIdx.x;   // j < i inside the diagonal tile
+    // 9 flop per pair (3 differences, 3 products, 2 sums, 1 comparison — SURVEY 8d); the products and sums are issued as
+    // one multiply and two explicit fused multiply-adds (the test only has to be a SUPERSET of the reference's
+    // sqrt(d^2) < collision_range, and the 1e-9 inflation of cr^2 is 10^7 times the rounding difference)
+#pragma unroll 4
     for (int k = 0; k < jmax; k++) {
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
-        const double d2 = ex * ex + ey * ey + ez * ez;
+        const double d2 = fma(ez, ez, fma(ey, ey, ex * ex));
         if (d2 < cr2i) {
             const int kk = amc_push_candidate(i, j0 + k, max_cand, cnt, D);
             if (kk >= 0)
@@ -262,7 +266,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
     D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.sd = c->W.cand_s; D.epoch = c->sweep_epoch;
     D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen;
     amc_prof_begin(c, AMC_K_DETECT);
-    if (c->allpairs) {
+    if (c->detect_ap) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);
         const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
         if (nblocks > 0)

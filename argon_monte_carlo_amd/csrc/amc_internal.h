@@ -141,7 +141,8 @@ struct amc_ctx {
     char *w_slab;             // the one allocation W's arrays are carved from
     amc_temp_ws T;
     amc_temp_dev_ws TD;
-    bool allpairs;
+    bool allpairs;            // no detection grid at all (single cells, N <= 4096): all-pairs detector, brute-force validation
+    bool detect_ap;           // candidates come from the LDS-tiled all-pairs kernel (always without a grid; with one when detect_mode == 2)
     // outputs
     amc_out out;
     amc_path_record *d_rec;

@@ -555,7 +555,7 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
         Aw.wide_per = (int)std::min<long long>(std::max<long long>(per, 1), 64);
     }
     amc_prof_cancel(c);                 // (the caller's bracket is re-opened below, around the kernel it is named after)
-    amc_prof_begin(c, AMC_K_PAIRS_WIDE);
+    amc_prof_begin(c, AMC_K_CLUSTERS_WIDE);
     amc_launch_clusters_wide(c, Aw);
     amc_prof_end(c);
     if (getenv("AMC_CW_TWICE")) {       // timing experiment only (the results of the step are garbage): the same kernel again, warm

@@ -29,11 +29,12 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 BYTES_PER_PARTICLE_STEP = 137    # 81 B read + 56 B written by a complete timestep(dt)
 # algorithmic bytes per particle for each kernel class (DESIGN.md "kernels")
-ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bin_scatter": 24, "bounds": 24, "resolve": 24}
-KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_lists",
-                   "detect": "k_detect_lists", "resolve": "k_resolve<GEOM,0> (first launch of the sweep)",
-                   "bounds": "k_stream (bounds-only pass)", "validate": "k_validate", "resolve_more": "k_resolve<GEOM,1>",
+ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bounds": 24}
+KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_lists / k_kin_pack / k_kin_unpack (list build)",
+                   "detect": "k_detect_lists", "resolve": "k_resolve<GEOM,0> (ordered workgroup)",
+                   "bounds": "k_stream (bounds-only pass)", "clusters_wide": "k_clusters_wide",
                    "commit": "k_commit", "allgather": "all-gather (RCCL)"}
+SWEEP_CLASSES = ("bin_count", "detect", "clusters_wide", "resolve", "commit")     # the p-p pair sweep (24 B per particle)
 
 WORKLOADS = {
     "cube_1e5": ("cube", 100_000),
@@ -43,7 +44,12 @@ WORKLOADS = {
     # BASELINE configs[3]: Temperature_Pore_MC energised walls; every step hands the wall hits to the host, which draws
     # the re-emission directions from the two Mersenne Twisters in particle order and evaluates mpmath.quad per gap hit
     "temp_1e6": ("temp", 1_000_000),
+    # the LDS-tiled ALL-PAIRS detector (k_detect_allpairs: what the reference's O(n^2) pairwise loop, Pore:168-174, maps to
+    # directly) in front of the same resolve: reported against the fp64 vector peak, 9 flop per unordered pair
+    "cube_allpairs_4096": ("cube", 4096),
+    "cube_allpairs_1e5": ("cube", 100_000),
 }
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (MI355X_MICROARCH.md / SURVEY 8d)
 
 
 def make_workload(name, n_override=None, device=0):
@@ -55,6 +61,8 @@ def make_workload(name, n_override=None, device=0):
     if kind == "cube":
         p, c = PR.cube_params_for_n(n, device=device)
         init = IC.cube_ic(p, c, seed=127)
+        if "allpairs" in name:
+            p.detect_mode = 2
     else:
         p, c = PR.pore_params(n=n, device=device, energised=(kind == "temp"))
         init = IC.pore_ic(p, c, seed=17)
@@ -100,7 +108,7 @@ def committed_traffic(workload, kclass, tag):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{tag}_pmc_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
-    needle = {"resolve": "k_resolve<", "detect": "k_detect_lists", "drift_walls": "k_stream", "validate": "k_validate",
+    needle = {"resolve": "k_resolve<", "detect": "k_detect_lists", "drift_walls": "k_stream", "clusters_wide": "k_clusters_wide",
               "commit": "k_commit"}.get(kclass)
     kern = json.load(open(path)).get("kernels", {})
     for name, v in kern.items():
@@ -135,7 +143,7 @@ def spawn_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round-tag", default="r01", help="prefix of the committed profile files to take `traffic` from")
+    ap.add_argument("--round-tag", default="r02", help="prefix of the committed profile files to take `traffic` from")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
@@ -298,18 +306,45 @@ def main():
         n_local = n_total // world if world > 1 else n_total
         dom = max(((k, v) for k, v in kt.items() if v[1] > 0 and k != "allgather"), key=lambda kv: kv[1][0], default=(None, (0, 0)))
         roof = None
+        if dom[0] is not None and "allpairs" in args.workload and kt.get("detect", (0, 0))[1] > 0:
+            dom = ("detect", kt["detect"])      # these workloads exist to report the all-pairs detector, dominant or not
         if dom[0] is not None:
             k, (ms, cnt) = dom
             avg_s = ms / cnt * 1e-3
-            per_particle = ALGO_BYTES.get(k, 24)
-            units = n_local if k in ("drift_walls", "bounds") else n_total
-            ach = per_particle * units / avg_s / 1e9
-            roof = {"kernel": KERNEL_OF_CLASS.get(k, k), "kernel_class": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
-                    "algorithmic_bytes_per_launch": per_particle * units,
-                    "per_kernel_avg_us": {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]},
-                    "whole_step_frac_of_hbm_peak": BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
-        if roof is not None:
+            avg_us = {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]}
+            allpairs = "allpairs" in args.workload
+            if k == "detect" and allpairs:
+                # the all-pairs detector: fp64 vector work, 9 flop per unordered pair
+                flops = 9.0 * n_total * (n_total - 1) / 2.0
+                ach = flops / avg_s / 1e12
+                roof = {"kernel": "k_detect_allpairs", "kernel_class": k, "bound": "fp64_valu", "achieved": ach,
+                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                        "avg_launch_us": avg_s * 1e6, "algorithmic_flops_per_launch": flops}
+            else:
+                # algorithmic bytes of the dominant kernel: a complete timestep for the streaming pass, the positions
+                # (24 B per particle) for every kernel of the pair sweep — whose wide-cluster / ordered-workgroup
+                # kernels touch a few hundred KB and are bound by LATENCY (chains of dependent round trips), so that this
+                # fraction prices their time against the sweep's data, not their own traffic
+                per_particle = ALGO_BYTES.get(k, 24)
+                units = n_local if k in ("drift_walls", "bounds") else n_total
+                ach = per_particle * units / avg_s / 1e9
+                roof = {"kernel": KERNEL_OF_CLASS.get(k, k), "kernel_class": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_s * 1e6,
+                        "algorithmic_bytes_per_launch": per_particle * units}
+                if k in ("clusters_wide", "resolve", "commit"):
+                    roof["note"] = "latency-bound kernel (dependent scattered round trips on a few hundred candidates): priced at the pair sweep's 24 B per particle"
+            roof["per_kernel_avg_us"] = avg_us
+            roof["whole_step_frac_of_hbm_peak"] = BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS
+            # the whole pair sweep (list build outside the streaming pass, detect, wide clusters, ordered workgroup, commit)
+            # against its 24 B per particle, and the streaming pass against its 137 B: the two numbers the north star names
+            sweep_us = sum(v for kk, v in avg_us.items() if kk in SWEEP_CLASSES and v)
+            if sweep_us > 0:
+                g = 24.0 * n_total / (sweep_us * 1e-6) / 1e9
+                roof["pair_sweep"] = {"avg_us": sweep_us, "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 24}
+            if avg_us.get("drift_walls"):
+                g = 137.0 * n_local / (avg_us["drift_walls"] * 1e-6) / 1e9
+                roof["streaming_pass"] = {"avg_us": avg_us["drift_walls"], "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 137}
+        if roof is not None and roof["bound"] == "hbm":
             roof["traffic"], roof["traffic_source"] = committed_traffic(args.workload, roof["kernel_class"], args.round_tag)
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,

@@ -312,12 +312,12 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 #define AMC_K_BIN_SCAN 2         /* reserved (no such pass: the lists need neither scan nor scatter) */
 #define AMC_K_BIN_SCATTER 3      /* reserved */
 #define AMC_K_DETECT 4
-#define AMC_K_RESOLVE 5          /* k_resolve, first launch of a sweep (claim, clusters, emulation; small sweeps: everything) */
+#define AMC_K_RESOLVE 5          /* k_resolve: the ordered workgroup (entangled remainder, later rounds, commit of a small sweep) */
 #define AMC_K_BOUNDS 6
-#define AMC_K_VALIDATE 7         /* k_validate (wide first-round validation)                                    */
-#define AMC_K_RESOLVE_MORE 8     /* k_resolve continuation (further rounds after a merge)                       */
-#define AMC_K_COMMIT 9           /* k_commit                                                                    */
-#define AMC_K_PAIRS_WIDE 10      /* k_pairs_wide: isolated pairs of a large sweep, before the ordered workgroup   */
+#define AMC_K_VALIDATE 7         /* reserved (validation happens inside k_clusters_wide / k_resolve)            */
+#define AMC_K_RESOLVE_MORE 8     /* reserved (later rounds run inside k_resolve)                                */
+#define AMC_K_COMMIT 9           /* k_commit: wide commit of a large sweep                                      */
+#define AMC_K_CLUSTERS_WIDE 10   /* k_clusters_wide: every small cluster emulated and validated wide, before the ordered workgroup */
 #define AMC_K_COUNT 12
 int amc_profile(amc_ctx *ctx, int enable);
 int amc_kernel_times(amc_ctx *ctx, double *total_ms /*[AMC_K_COUNT]*/, int64_t *launches /*[AMC_K_COUNT]*/);

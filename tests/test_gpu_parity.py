@@ -810,8 +810,37 @@ def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
     kt = eng.kernel_times()
     eng.profile(False)
     assert ncand > 640
-    assert kt["pairs_wide"][1] >= 6 and kt["commit"][1] >= 4, kt
+    assert kt["clusters_wide"][1] >= 6 and kt["commit"][1] >= 4, kt
     eng.close()
+
+
+def test_allpairs_detector_in_front_of_the_grid_resolve_vs_oracle(Engine, O):
+    """detect_mode 2 above 4096 particles: candidates from the LDS-tiled all-pairs kernel (what the reference's pairwise
+    loop, Pore:168-174, maps to directly), resolved by the same wide-cluster / ordered-workgroup kernels as the binned
+    detector's — state and counters equal the oracle's bit for bit, and equal the binned detector's."""
+    p, c = PR.cube_params_for_n(20_000)
+    init = IC.cube_ic(p, c, seed=3)
+    runs = {}
+    for mode in (2, 1):
+        p.detect_mode = mode
+        eng = Engine(p)
+        eng.upload(*init)
+        orc = O.Oracle(p, mode="mul")
+        orc.upload(*init)
+        npp = 0
+        for s in range(5):
+            st = eng.timestep(c["dt"])
+            rc, so = orc.timestep(c["dt"])
+            assert rc == 0
+            for k in ("n_pp", "n_paths", "n_fp_errors"):
+                assert st[k] == so[k], (mode, s, k, st, so)
+            npp += st["n_pp"]
+            assert_state_equal(eng.download(), orc.state(), ("allpairs detector", mode, s))
+        assert npp > 100
+        runs[mode] = eng.download()
+        eng.close()
+    for k in runs[1]:
+        assert np.array_equal(runs[1][k], runs[2][k]), k
 
 
 def test_candidate_overflow_in_the_large_sweep_plan_is_reported(Engine):
