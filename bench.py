@@ -75,30 +75,79 @@ def make_workload(name, n_override=None, device=0):
 
 
 def cpu_baseline(workload, budget_s=12.0):
-    """The oracle (oracle/amc_oracle.c, `mul` variant) on one host core, on a bounded number of steps of the SAME
-    workload.  Reported next to the GPU number; it is a baseline, not the target."""
+    """The oracle (oracle/amc_oracle.c, `mul` variant) on the host, on a bounded number of steps of the SAME workload.
+    Reported next to the GPU number; it is a baseline, not the target.  Three figures:
+      * `cpu_baseline`           the faithful port on the cores the reference's algorithm can use for this geometry: ONE for
+                                 the cube (Open_Air_Cube_MC.py's cell loop is serial, Cube:231-336), ALL for the pore (OpenMP
+                                 threads over the disjoint cells of a colour group = the Pool.starmap structure, Pore:545-549);
+      * `cpu_baseline_1core`     the same port on one core (always);
+      * `cpu_baseline_all_cores` all host cores (cube: the Pore script's colouring applied to the cube's cells — a
+                                 different processing order than the reference's serial loop, timing only)."""
     from oracle import oracle as O
     p, c, init = make_workload(workload)
+    kind = WORKLOADS[workload][0]
+    ncores = os.cpu_count() or 1
+
+    def timed(one, budget):
+        one()                                       # warm-up (page faults)
+        t0 = time.perf_counter()
+        steps = 0
+        while True:
+            one()
+            steps += 1
+            el = time.perf_counter() - t0
+            if el > budget or steps >= 2000:
+                return steps, el
+
     orc = O.Oracle(p, mode="mul")
     orc.upload(*init)
-    if WORKLOADS[workload][0] == "temp":
+    if kind == "temp":
         import random
         from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
         sampler, energies = DirectionSampler(np.random.RandomState(17), random.Random(17)), SurfaceEnergies(c)
         one = lambda: orc.temp_timestep(c["dt"], sampler, energies)     # noqa: E731
     else:
         one = lambda: orc.timestep(c["dt"])                             # noqa: E731
-    one()                                       # warm-up (page faults)
+    steps, el = timed(one, budget_s)
+    serial = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+              "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle/amc_oracle.c single thread"}
+    out = {"cpu_baseline_1core": serial}
+    if kind == "temp":
+        out["cpu_baseline"] = serial                # (the energised step's host part is sequential by construction)
+        return out
+    par = O.Oracle(p, mode="mul")
+    par.upload(*init)
+    steps, el = timed(lambda: par.timestep_par(c["dt"], threads=ncores), budget_s)
+    allc = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
+            "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle sweep with OpenMP threads over the "
+                      "disjoint cells of a colour group" + (" (the Pore script's colouring on the cube's cells: NOT the "
+                      "reference's serial cube order)" if kind == "cube" else " (= the reference's Pool.starmap structure)")}
+    out["cpu_baseline_all_cores"] = allc
+    out["cpu_baseline"] = serial if kind == "cube" else allc
+    return out
+
+
+def cpu_baseline_python_mp(n=100_000, steps=3):
+    """The reference's own parallel STRUCTURE in NumPy + multiprocessing (oracle/pymp_structure.py: 8 colour groups, one
+    boolean mask per cell over all N particles, one Pool task per cell, Pool(cpu_count() + 1), a fresh pool per group —
+    Pore:520-549), validated against the reference's step dump, timed on this host for `steps` steps of the specular pore
+    at N = n.  The like-for-like "Python/multiprocessing" number of the north star."""
+    from argon_monte_carlo_amd import ic as IC
+    from argon_monte_carlo_amd import params as PR
+    from oracle import pymp_structure as PM
+    p, c = PR.pore_params(n=n)
+    init = IC.pore_ic(p, c, seed=17)
+    s = PM.PyMpStepper(p)
+    s.upload(*init)
     t0 = time.perf_counter()
-    steps = 0
-    while True:
-        one()
-        steps += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or steps >= 2000:
-            break
-    return {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle/amc_oracle.c single thread"}
+    npp = 0
+    for _ in range(steps):
+        npp += s.timestep(c["dt"])["n_pp"]
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "workers": (os.cpu_count() or 1) + 1,
+            "sample": f"{steps} steps (no warm-up) of the specular pore at N={n} in {el:.1f} s, {npp} p-p collisions; "
+                      "oracle/pymp_structure.py (NumPy-scalar pair loop, full per-cell boolean masks, fresh Pool per colour group)"}
 
 
 def committed_traffic(workload, kclass, tag):
@@ -150,6 +199,7 @@ def main():
     ap.add_argument("--workload", default="cube_1e5", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the particle count per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-python-mp-baseline", action="store_true", help="skip the NumPy + multiprocessing leg (~30 s)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
     ap.add_argument("--sorted-ic", action="store_true", help="experiment: upload the particles in spatial (cell) order")
@@ -356,7 +406,9 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            out.update(cpu_baseline(args.workload))
+            if not args.no_python_mp_baseline:
+                out["cpu_baseline_python_mp"] = cpu_baseline_python_mp()
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

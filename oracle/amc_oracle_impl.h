@@ -350,6 +350,121 @@ int ORC(pore_sweep)(const amc_params *P, orc_state *S, orc_sink *sink, int32_t s
     return rc;
 }
 
+/* ---- all host cores: the reference's own parallel structure (Pore:520-549: the cells of one colour group are disjoint
+ * and go to a pool of workers, the eight groups follow each other), with OpenMP threads in place of the Pool's processes.
+ * Inside a group the order of the cells only decides the order in which completed paths are appended, not the state, so
+ * the result equals ORC(pore_sweep)'s (tests/test_oracle_parallel.py); completed paths are counted, not recorded.
+ * cube != 0 applies the same colouring to the Cube script's cells (l*d - ov < v < (l+1)*d, colour = parity of l): the
+ * reference's cube loop is SERIAL (Cube:231-336, lexicographic with stale masks), so for that geometry this is what all
+ * cores could do with the Pore script's scheme — a timing baseline with a different processing order, not a port.  */
+static int ORC(axis_cell_cube)(double v, int grp, int nlayers, double d, double ov)
+{
+    double f = floor(v / d);
+    for (int dk = 0; dk <= 1; dk++) {
+        long l = (long)f + dk;
+        if (l < 0 || l >= nlayers || ((l & 1) != grp)) continue;
+        double lo = (double)l * d - ov, hi = (double)(l + 1) * d;
+        if (lo < v && v < hi) return (int)(l >> 1);
+    }
+    return -1;
+}
+
+int ORC(sweep_par)(const amc_params *P, orc_state *S, int cube, int64_t *npp, int64_t *npaths, int64_t *npairs_tested)
+{
+    const int64_t n = S->n;
+    const int hx = cube ? (P->nx + 1) / 2 : P->nx, hy = cube ? (P->ny + 1) / 2 : P->ny, hz = cube ? (P->nz + 1) / 2 : P->nz / 2;
+    const int64_t ncell = (int64_t)hx * hy * hz;
+    ORC(memb) *mem = (ORC(memb) *)malloc(sizeof(ORC(memb)) * (size_t)(n + 1));
+    int64_t *pcell = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    int64_t *cstart = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncell + 2));
+    int64_t *seg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ncell + 2));
+    int rc_all = 0;
+    int64_t tot_pp = 0, tot_paths = 0, tot_pairs = 0;
+    for (int gx = 0; gx < 2; gx++)
+        for (int gy = 0; gy < 2; gy++)
+            for (int gz = 0; gz < 2; gz++) {
+                memset(cstart, 0, sizeof(int64_t) * (size_t)(ncell + 1));
+#pragma omp parallel for schedule(static)
+                for (int64_t p = 0; p < n; p++) {
+                    pcell[p] = -1;
+                    int lx = cube ? ORC(axis_cell_cube)(S->x[p], gx, P->nx, P->dx, P->overlap_x) : ORC(axis_cell)(S->x[p], gx, P->nx, P->nx, P->dx, P->overlap_x);
+                    if (lx < 0) continue;
+                    int ly = cube ? ORC(axis_cell_cube)(S->y[p], gy, P->ny, P->dy, P->overlap_y) : ORC(axis_cell)(S->y[p], gy, P->ny, P->ny, P->dy, P->overlap_y);
+                    if (ly < 0) continue;
+                    int lz = cube ? ORC(axis_cell_cube)(S->z[p], gz, P->nz, P->dz, P->overlap_z) : ORC(axis_cell)(S->z[p], gz, P->nz / 2, 0, P->dz, P->overlap_z);
+                    if (lz < 0) continue;
+                    pcell[p] = ((int64_t)lx * hy + ly) * hz + lz;
+                }
+                for (int64_t p = 0; p < n; p++)
+                    if (pcell[p] >= 0) cstart[pcell[p] + 1]++;
+                for (int64_t c = 0; c < ncell; c++) cstart[c + 1] += cstart[c];
+                const int64_t cnt = cstart[ncell];
+                for (int64_t c = 0; c <= ncell; c++) seg[c] = cstart[c];
+                for (int64_t p = 0; p < n; p++) {                 /* stable: members of a cell in ascending particle index */
+                    if (pcell[p] < 0) continue;
+                    int64_t k = cstart[pcell[p]]++;
+                    mem[k].cell = pcell[p];
+                    mem[k].idx = (int32_t)p;
+                }
+                (void)cnt;
+                const int phase = 16 + 4 * gx + 2 * gy + gz;
+#pragma omp parallel reduction(+ : tot_pp, tot_paths, tot_pairs) reduction(| : rc_all)
+                {
+                    int64_t cap = 64;
+                    double *buf = (double *)malloc(sizeof(double) * 10 * (size_t)cap);
+                    uint8_t *fbuf = (uint8_t *)malloc((size_t)cap);
+                    int32_t *ibuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+                    amc_path_record recs[8];
+#pragma omp for schedule(dynamic, 16)
+                    for (int64_t c = 0; c < ncell; c++) {
+                        const int64_t s = seg[c], m = seg[c + 1] - seg[c];
+                        if (m < 2) continue;
+                        if (m > cap) {
+                            cap = 2 * m;
+                            free(buf); free(fbuf); free(ibuf);
+                            buf = (double *)malloc(sizeof(double) * 10 * (size_t)cap);
+                            fbuf = (uint8_t *)malloc((size_t)cap);
+                            ibuf = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+                        }
+                        orc_sink sink = {recs, 0, 0, 0};            /* capacity 0: every completed path counts as overflow */
+                        int64_t pp = 0;
+                        rc_all |= ORC(run_cell)(P, S, mem + s, m, &sink, 0, phase, c, &pp, buf, fbuf, ibuf);
+                        tot_pp += pp;
+                        tot_paths += sink.overflow;
+                        tot_pairs += m * (m - 1) / 2;
+                    }
+                    free(buf); free(fbuf); free(ibuf);
+                }
+            }
+    free(mem); free(pcell); free(cstart); free(seg);
+    if (npp) *npp += tot_pp;
+    if (npaths) *npaths += tot_paths;
+    if (npairs_tested) *npairs_tested += tot_pairs;
+    return rc_all;
+}
+
+/* one step with the parallel sweep (specular geometries): per-particle stages as in ORC(timestep) */
+int ORC(timestep_par)(const amc_params *P, orc_state *S, double dt, amc_step_stats *st)
+{
+    amc_step_stats z;
+    memset(&z, 0, sizeof z);
+    int rc = 0;
+    const int cube = P->geometry == AMC_GEOM_CUBE;
+    ORC(drift)(P, S, dt, !cube);
+    if (cube) {
+        ORC(cube_walls)(P, S);
+    } else {
+        orc_sink none = {0, 0, 0, 0};
+        rc = ORC(pore_walls)(P, S, &none, 0, &z.n_wall);
+        z.n_paths += none.overflow;
+        if (!rc) z.n_oob_walls = ORC(bounds)(P, S, 0);
+    }
+    if (!rc) rc = ORC(sweep_par)(P, S, cube, &z.n_pp, &z.n_paths, &z.n_candidates);
+    if (!rc && !cube) z.n_oob_pp = ORC(bounds)(P, S, 0);
+    if (st) *st = z;
+    return rc;
+}
+
 /* a3 — Cube cell loop, Cube:231-336: lexicographic (x,y,z) cells; in_x_layer is evaluated once per x_layer,
  * in_y_layer once per (x_layer,y_layer), in_z_layer per cell — all from the state at that moment; every cell
  * gathers from / scatters to the global arrays before the next one runs.                                     */

@@ -105,6 +105,18 @@ class Oracle:
         self.last_rc = rc
         return rc, st.as_dict()
 
+    def timestep_par(self, dt, threads=None):
+        """One step with the p-p sweep spread over the host's cores (OpenMP threads over the disjoint cells of a colour
+        group — the reference's Pool.starmap structure, Pore:545-549).  Specular geometries; completed paths are
+        counted, not recorded.  For the pore the state equals timestep()'s; for the cube the colouring is NOT the
+        reference's serial order (see amc_oracle_impl.h)."""
+        if threads:
+            os.environ["OMP_NUM_THREADS"] = str(int(threads))
+        st = AmcStepStats()
+        rc = self._fn("timestep_par")(C.byref(self.p), C.byref(self._state), C.c_double(dt), C.byref(st))
+        self.step += 1
+        return rc, st.as_dict()
+
     def drift(self, dt, save_prior=True):
         self._fn("drift")(C.byref(self.p), C.byref(self._state), C.c_double(dt), C.c_int(int(save_prior)))
 
