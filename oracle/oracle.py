@@ -196,15 +196,29 @@ class Oracle:
         self._temp_errs += nerr.value
         return dpz[:nh], dE[:nh]
 
+    def _own_host_objects(self, sampler, energies):
+        """The oracle's own direction sampler / surface energies (oracle/temp_host.py) on the SAME two random generators and
+        constants the caller's objects carry — the product's classes are only looked at for those, never called."""
+        from oracle import temp_host as TH
+        key = (id(sampler), id(energies))
+        if getattr(self, "_host_key", None) != key:
+            d = sampler if isinstance(sampler, TH.Directions) else TH.Directions(sampler.np_rng, sampler.py_rng)
+            e = energies if isinstance(energies, TH.Energies) else TH.Energies(energies)
+            self._host_key, self._host_objs = key, (d, e, sampler, energies)     # (keeps the ids alive)
+        return self._host_objs[0], self._host_objs[1]
+
     def temp_timestep(self, dt, sampler, energies):
-        """One iteration of Temp:662-853.  Returns (stats dict, momentum, energy_cold, energy_hot, had flags)."""
-        from argon_monte_carlo_amd.energised import drive_energised_cases
+        """One iteration of Temp:662-853.  Returns (rc, stats dict, momentum, energy_cold, energy_hot, had flags).
+        `sampler` / `energies` may be the product's objects: only their random generators and constants are used, the
+        host loop itself is the oracle's own (oracle/temp_host.py)."""
+        from oracle import temp_host as TH
+        directions, own_energies = self._own_host_objects(sampler, energies)
         before = self._sink.n
         self._temp_wall_count = 0
         self._temp_errs = 0
         self.drift(dt, True)                                        # Temp:672-683
         self._temp_errs += self.temp_specular()                     # Temp:693-703
-        res = drive_energised_cases(self, sampler, energies)        # Temp:705-758
+        res = TH.run_cases(self, directions, own_energies)          # Temp:705-758
         oob1 = self.bounds(True)                                    # Temp:804
         rc, npp, _ = self.sweep()                                   # Temp:813-842
         oob2 = self.bounds(True)                                    # Temp:844
