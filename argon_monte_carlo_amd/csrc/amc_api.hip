@@ -214,7 +214,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr; c->w_slab = nullptr;
     c->mg_count_pp = true;
-    c->lazy_pending = false;
+    c->lazy_pending = false; c->commit_pending = false; c->commit_defer = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
     c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
     c->plan_small = AMC_PLAN_SMALL;
@@ -284,7 +284,6 @@ int amc_create(amc_ctx **out, const amc_params *p)
                 };
                 take(&W.ctl, 64); take(&W.wctl, 64);
                 take(&W.cand4, (size_t)W.max_cand); take(&W.cand_s, (size_t)W.max_cand);
-                take(&W.cst, (size_t)RS_CST_DOUBLES * W.max_cand);
                 take(&W.sl_meta, ms); take(&W.sl_hits, ms); take(&W.sl_moved, ms);
                 take(&W.sl_state, (size_t)RS_SLOT_DOUBLES * ms);
                 take(&W.sl_label, ms); take(&W.sl_tmp, ms); take(&W.sl_dirty, ms); take(&W.order, ms);
@@ -452,6 +451,10 @@ static void fold_banks(amc_dev_counters *h, const amc_counter_bank *b)
 
 int amc_read_counters(amc_ctx *c, amc_dev_counters *h)
 {
+    if (c->commit_pending) {            // the last sweep's paths / counters are not in yet: commit it now (its results stay deferred)
+        AMC_HIP(c, amc_launch_commit(c));
+        c->commit_pending = false;
+    }
     amc_counter_bank banks[AMC_COUNTER_BANKS];
     amc_stage st(c);
     AMC_HIP(c, st.get(h, c->d_cnt, sizeof *h));
@@ -501,6 +504,10 @@ int amc_finish_stats(amc_ctx *c, amc_step_stats *out)
 // sweep results deferred to the next streaming pass: write them now (before anything else reads the particle arrays)
 int amc_flush(amc_ctx *c)
 {
+    if (c->commit_pending) {            // (before the results are applied: the commit leaves the number of deferred slots)
+        AMC_HIP(c, amc_launch_commit(c));
+        c->commit_pending = false;
+    }
     if (!c->lazy_pending) return AMC_OK;
     AMC_HIP(c, amc_launch_apply(c));
     c->lazy_pending = false;

@@ -264,8 +264,11 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         // ---- 1. my candidate and the graph around it -----------------------------------------------------------------
         int4 c4 = make_int4(0, 0, -1, -1);
         int head_i = -1, head_j = -1;
+        amc_particle pre_j, pre_i;          // state of both particles, requested together with the graph heads (one round trip)
         if (valid) {
             c4 = (k == k_first) ? c4_first : W.cand4[k];
+            pre_j = rs_load_particle(A.S, c4.y);
+            pre_i = rs_load_particle(A.S, c4.x);
             head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
             head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
         }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     cw_init_slot(W, sj, pj, lab, g + 1);
                     cw_init_slot(W, si, pi, lab, g + 1);
                     W.cand_s[k] = make_int4(si, sj, 1, 0);
-                    rs_emulate_pair<GEOM>(A, wc, k, pj, pi, sj, si, &wd);
+                    rs_emulate_pair<GEOM>(A, wc, pre_j, pre_i, pj, pi, sj, si, &wd);
                 } else {
                     amc_particle q[3];
                     int pidx[3], slot[3];

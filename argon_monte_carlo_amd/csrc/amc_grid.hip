@@ -82,31 +82,6 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
     return -1;
 }
 
-AMC_DEV double amc_state_elem(const amc_state &S, int p, int e)
-{
-    switch (e) {
-    case 0: return S.x[p]; case 1: return S.y[p]; case 2: return S.z[p];
-    case 3: return S.vx[p]; case 4: return S.vy[p]; case 5: return S.vz[p];
-    case 6: return S.d[p]; case 7: return S.dx[p]; case 8: return S.dy[p]; case 9: return S.dz[p];
-    default: return S.flag[p] ? 1.0 : 0.0;
-    }
-}
-
-// state gather for the candidates found by the lanes of this wave, done by the WHOLE wave: lane e < 22 moves element
-// e of the pair (11 per particle), so a candidate costs one load + one store instruction instead of 44 serial ones
-AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int my_j, const amc_state &S, double *cst)
-{
-    const int lane = threadIdx.x & 63;
-    while (found) {
-        const int src = __ffsll((long long)found) - 1;
-        found &= found - 1;
-        const int k = __shfl(my_k, src, 64);
-        const int pi = __shfl(my_i, src, 64), pj = __shfl(my_j, src, 64);     // (i > j), straight from the finder's registers
-        if (k < 0 || lane >= 22) continue;
-        cst[(size_t)k * RS_CST_DOUBLES + lane] = amc_state_elem(S, lane / 11 ? pi : pj, lane % 11);
-    }
-}
-
 // ---- binned detection: one thread per particle ----------------------------------------------------------------------------
 // Each particle walks its own cell's list (the part inserted before it) and the lists of the lower-numbered cells its
 // +-collision_range box overlaps; every close pair is met exactly once and stored as (larger index, smaller index).
@@ -114,25 +89,12 @@ AMC_DEV void amc_wave_gather(unsigned long long found, int my_k, int my_i, int m
 // whatever their width, index-ordered ones at ~2e11/s — the kernel's cost is its number of random requests
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
 __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
-                                                      int max_cand, amc_dev_counters *cnt, amc_state S, double *cst, amc_adj D)
+                                                      int max_cand, amc_dev_counters *cnt, amc_adj D)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    int my_k = -1, my_i = 0, my_j = 0;   // a lane finds at most a handful of pairs; the (rare) 2nd+ ones are gathered right away
-    bool pending = false;
     if (p < n) {
         const double4 me = B.rec[p];
-        auto found_pair = [&](int q) {
-            if (!pending) {                        // first pair of this lane: pushed at the end, together with the gather
-                pending = true; my_i = (int)p > q ? (int)p : q; my_j = (int)p > q ? q : (int)p;
-                return;
-            }
-            const int kk = amc_push_candidate((int)p, q, max_cand, cnt, D);
-            if (kk >= 0) {
-                const int hi = (int)p > q ? (int)p : q, lo = (int)p > q ? q : (int)p;
-                for (int e = 0; e < 22; e++)       // second pair of this lane: gather it alone (rare)
-                    cst[(size_t)kk * RS_CST_DOUBLES + e] = amc_state_elem(S, e / 11 ? hi : lo, e % 11);
-            }
-        };
+        auto found_pair = [&](int q) { amc_push_candidate((int)p, q, max_cand, cnt, D); };
         // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
         // every same-cell pair is thereby met exactly once, by the later-inserted particle, and the head is not needed);
         // slots 1..8: the other cells my box overlaps, but only those with a SMALLER cell id: two particles closer than
@@ -179,29 +141,13 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
                 }
         }
     }
-    unsigned long long found = __ballot(pending);
-    if (found) {
-        // the state of the first found pair (most waves have at most one) is requested BEFORE the push, so that its
-        // loads and the counter's atomic are in flight together: one memory round trip less at the tail of the kernel
-        const int lane = threadIdx.x & 63;
-        const int src0 = __ffsll((long long)found) - 1;
-        const int pi0 = __shfl(my_i, src0, 64), pj0 = __shfl(my_j, src0, 64);
-        double v0 = 0.0;
-        if (lane < 22) v0 = amc_state_elem(S, lane / 11 ? pi0 : pj0, lane % 11);
-        if (pending) my_k = amc_push_candidate(my_i, my_j, max_cand, cnt, D);
-        const int k0 = __shfl(my_k, src0, 64);
-        if (k0 >= 0 && lane < 22) cst[(size_t)k0 * RS_CST_DOUBLES + lane] = v0;
-        found &= found - 1;
-        if (found) amc_wave_gather(found, my_k, my_i, my_j, S, cst);
-    }
 }
 
 // ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
 #define AP_T 256
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
                                                           const double *__restrict__ z, int n, int ntiles, double cr2i,
-                                                          int max_cand, amc_dev_counters *cnt, amc_state S, double *cst,
-                                                          amc_adj D)
+                                                          int max_cand, amc_dev_counters *cnt, amc_adj D)
 {
     // blockIdx.x enumerates the lower triangle of tile pairs: (bi, bj) with bj <= bi
     int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
@@ -229,12 +175,7 @@ __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restri
     for (int k = 0; k < jmax; k++) {
         const double ex = tx[k] - xi, ey = ty[k] - yi, ez = tz[k] - zi;
         const double d2 = fma(ez, ez, fma(ey, ey, ex * ex));
-        if (d2 < cr2i) {
-            const int kk = amc_push_candidate(i, j0 + k, max_cand, cnt, D);
-            if (kk >= 0)
-                for (int e = 0; e < 22; e++)
-                    cst[(size_t)kk * RS_CST_DOUBLES + e] = amc_state_elem(S, e / 11 ? i : (j0 + k), e % 11);
-        }
+        if (d2 < cr2i) amc_push_candidate(i, j0 + k, max_cand, cnt, D);
     }
 }
 
@@ -271,10 +212,10 @@ hipError_t amc_launch_detect(amc_ctx *c)
         const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
         if (nblocks > 0)
             hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
-                               c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
+                               c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
     } else {
         hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
-                           c->P.collision_range * 1.000001, c->W.max_cand, c->d_cnt, c->S, c->W.cst, D);
+                           c->P.collision_range * 1.000001, c->W.max_cand, c->d_cnt, D);
     }
     amc_prof_end(c);
     return hipGetLastError();

@@ -9,7 +9,6 @@
 #include "amc_device.h"
 
 #define RS_SLOT_DOUBLES 12    // x y z vx vy vz d dx dy dz flag(0/1) pad  — one slot's scratch state (96 bytes)
-#define RS_CST_DOUBLES 24     // 11 of particle j, 11 of particle i, 2 pad — one candidate's gathered state (192 bytes)
 
 // ---- SoA particle state in HBM (one allocation each, float64[n]; flag uint8[n]) --------------------------------
 struct amc_state {
@@ -56,6 +55,12 @@ struct amc_lazy {
 // memory round trips and of DISTINCT arrays (every array is a base pointer to fetch and to keep in scalar registers).
 // So what one thread handles at a time is ONE record (array of structures); only what the ordered workgroup scans in
 // bulk stays a plain array.
+// the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve_dev.h)
+struct amc_resolve_ctl {
+    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
+    int rounds, ncand, active, ok, edges_done;
+    int lazy_ns, nslots0, hist_begin, cur_round;
+};
 struct rs_event {             // a completed free path found by an emulation (64 bytes), emitted at commit
     int phase, i, j, which;
     long long cell;
@@ -64,9 +69,8 @@ struct rs_event {             // a completed free path found by an emulation (64
 };
 struct amc_resolve_ws {
     // candidates: cand4[k] = (i, j, next candidate in i's list, next candidate in j's list), i > j (particle indices);
-    // cand_s[k] = (slot of i, slot of j, done by the wide kernel, -); cst = state of both particles, gathered by detect
+    // cand_s[k] = (slot of i, slot of j, done by the wide kernel, -)
     int4 *cand4, *cand_s;
-    double *cst;              // [max_cand][RS_CST_DOUBLES]
     int max_cand;
     unsigned long long *adj_head;   // [n] (sweep epoch << 32) | last candidate pushed that touches the particle
     int *slot_of;             // [n] particle -> slot or -1
@@ -164,6 +168,8 @@ struct amc_ctx {
     volatile int *h_host_ncand;    // host-mapped word written by k_resolve (candidate count of the last sweep)
     int *d_host_ncand;             // its device address
     bool lazy_pending;             // sweep results wait in the slot arrays for the next streaming pass (or amc_flush)
+    bool commit_pending;           // the last sweep's commit (paths -> histograms, counters, overlay) waits for the next streaming pass (or amc_flush)
+    bool commit_defer;             // ... and that sweep's results stay in the slot arrays
     unsigned int sweep_epoch;      // tag of the degree counts of the current sweep (advanced by every detect launch)
     bool plan_split;               // launch plan of the current sweep, fixed when its detect kernel is launched
     int plan_small;                // candidate pairs up to which the single resolve kernel does the whole sweep
@@ -207,14 +213,11 @@ hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_apply(amc_ctx *c);                // write deferred sweep results to the particle arrays now
+hipError_t amc_launch_commit(amc_ctx *c);               // the pending commit as a kernel of its own
+struct amc_commit_args;
+amc_commit_args amc_make_commit_args(amc_ctx *c);       // amc_stream.hip
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
 hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg);
 hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack);
 int amc_kin_banks(void);         // banks of the velocity-change list in an exchange block
-// the resolve kernels' hand-over block (mirror of rs_shared in amc_resolve.hip)
-struct amc_resolve_ctl {
-    int nslots, nedges, nhist, nev, dirty, changed, nhits, nfp, ovf, nclusters, ncomplex;
-    int rounds, ncand, active, ok, edges_done;
-    int lazy_ns, nslots0, hist_begin, cur_round;
-};

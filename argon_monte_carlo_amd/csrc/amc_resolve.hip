@@ -34,6 +34,7 @@
 #include <algorithm>
 
 #include "amc_resolve_dev.h"
+#include "amc_commit_dev.h"
 
 #define RS_STAMP(slot)                                                                     \
     do {                                                                                   \
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 
     const bool wide = wide_ns >= 0;
     const int gen_off = wide ? 16 : 0;          // (the wide kernel tags its own re-emulations of a cluster with rounds 1, 2, 3)
-    const bool mono = (MODE == 2) || A.force_mono;      // commit in this kernel
+    const bool mono = (MODE == 2);      // commit in this kernel (no-grid mode); with a grid the commit is wide work of its own:
+                                        // it rides along with the next streaming pass or runs as k_commit
     const int nleft = s_left;
     // nothing left and nothing found by the wide kernel's validation: the sweep is resolved, only the commit remains
     const bool resolved = wide && nleft == 0 && !wide_dirty;
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
                 const int si = cs.x, sj = cs.y;
                 if (si < 0 || sj < 0 || si >= ns || sj >= ns) continue;
                 if (V.size[V.label[si]] != 2 || !vdirty[V.label[si]]) continue;
-                { const int4 c4 = W.cand4[k]; rs_emulate_pair<GEOM>(A, &sh, k, c4.y, c4.x, sj, si); }
+                { const int4 c4 = W.cand4[k]; rs_emulate_pair<GEOM>(A, &sh, rs_load_particle(A.S, c4.y), rs_load_particle(A.S, c4.x), c4.y, c4.x, sj, si); }
             }
         }
         RS_STAMP(7);
@@ -493,44 +495,12 @@ __global__ __launch_bounds__(256) void k_commit(rs_args A)
         }
         return;
     }
-    if (!ctl->active) return;
-    const bool ok = ctl->ok && !ctl->ovf;
-    const bool defer = ok && A.defer_commit;
-    const int ns = ctl->nslots < W.max_slots ? ctl->nslots : W.max_slots;
-    const int nh = ctl->nhist < W.max_hist ? ctl->nhist : W.max_hist;
-    int my_hits = 0, my_fp = 0;
-    for (int s = gtid; s < ns; s += gstride) {
-        const int p = W.sl_meta[s].x;
-        if (ok && A.count_pp) { const int hs = W.sl_hits[s]; my_hits += hs & 0xffff; my_fp += hs >> 16; }
-        if (defer || p < 0) continue;
-        if (ok && W.sl_moved[s]) {
-            rs_apply_slot(W, A.S, s, p);
-        }
-        W.slot_of[p] = -1;
-    }
-    // one atomic per wave instead of one per slot on a single counter word
-    for (int o = 32; o > 0; o >>= 1) { my_hits += __shfl_down(my_hits, o, 64); my_fp += __shfl_down(my_fp, o, 64); }
-    if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(&A.O.banks[amc_bank_id()].n_pp, (unsigned long long)my_hits);
-    if ((threadIdx.x & 63) == 0 && my_fp) atomicAdd(&A.O.banks[amc_bank_id()].n_fp_errors, (unsigned long long)my_fp);
-    if (ok)
-        for (int e = gtid; e < nh; e += gstride) {
-            const int g = W.ev_gen[e];
-            if (g == 0) continue;                                         // no completed path at this entry
-            const rs_event ev = W.ev[e];
-            if (g != W.sl_meta[ev.slot].z) continue;                    // event of an emulation that was redone since
-            const int owner = ev.which ? ev.i : ev.j;      // the particle whose free path completed
-            if (owner < A.lo || owner >= A.hi) continue;
-            amc_emit(A.O, ev.phase, ev.cell, ev.i, ev.j, ev.which, ev.val[0], ev.val[1], ev.val[2], ev.val[3]);
-        }
-    for (int h = gtid; h < nh; h += gstride) W.ov_head[rs_hist_cell(A, A.G, h)] = -1;   // overlay entries of this sweep
-    if (gtid == 0) {
-        amc_dev_counters *cnt = A.O.cnt;
-        cnt->n_candidates += (unsigned long long)ctl->ncand;
-        cnt->n_clusters += (unsigned long long)ctl->nclusters;
-        cnt->n_rounds += (unsigned long long)ctl->rounds;
-        if (!ok) cnt->flags |= 4ULL;
-        ctl->lazy_ns = defer ? ns : 0;
-    }
+    amc_commit_args C;
+    C.ctl = (amc_resolve_ctl *)W.ctl; C.hist = W.hist; C.ov_head = W.ov_head; C.ev_gen = W.ev_gen; C.ev = W.ev;
+    C.sl_meta = W.sl_meta; C.sl_hits = W.sl_hits; C.sl_moved = W.sl_moved; C.sl_state = W.sl_state; C.slot_of = W.slot_of;
+    C.max_slots = W.max_slots; C.max_hist = W.max_hist; C.lo = A.lo; C.hi = A.hi; C.count_pp = A.count_pp;
+    C.defer = A.defer_commit; C.nogrid = A.allpairs; C.enabled = 1;
+    amc_commit_part(C, A.O, A.G, A.S, gtid, gstride);
 }
 
 template <int GEOM>
@@ -546,7 +516,7 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     // the workgroup itself, a large one by the wide commit kernel.  Either plan is correct for any count.
     rs_args Aw = A;
     Aw.wide_plan = 1;
-    Aw.force_mono = c->plan_split ? 0 : 1;
+    Aw.force_mono = 0;
     {
         // candidates per wave of the wide kernel from the lagging count (with head room; more candidates = more passes)
         const long long lag = c->h_host_ncand ? *c->h_host_ncand : 0;
@@ -558,17 +528,14 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     amc_prof_begin(c, AMC_K_CLUSTERS_WIDE);
     amc_launch_clusters_wide(c, Aw);
     amc_prof_end(c);
-    if (getenv("AMC_CW_TWICE")) {       // timing experiment only (the results of the step are garbage): the same kernel again, warm
-        amc_prof_begin(c, AMC_K_VALIDATE);
-        amc_launch_clusters_wide(c, Aw);
-        amc_prof_end(c);
-    }
     amc_prof_begin(c, AMC_K_RESOLVE);
     hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, Aw);
-    if (!c->plan_split) return;
+    // the commit: deferred results -> it waits for the next streaming pass (or amc_flush); else a kernel of its own, now
+    c->commit_defer = A.defer_commit != 0;
+    if (A.defer_commit) { c->commit_pending = true; return; }
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(64), dim3(256), 0, c->stream, Aw);
+    hipLaunchKernelGGL(k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), 0, c->stream, Aw);
 }
 
 static rs_args rs_make_args(amc_ctx *c)
@@ -587,6 +554,16 @@ static rs_args rs_make_args(amc_ctx *c)
     A.lo = c->lo; A.hi = c->hi;
     A.inv_dx = c->P.dx > 0 ? 1.0 / c->P.dx : 0.0; A.inv_dy = c->P.dy > 0 ? 1.0 / c->P.dy : 0.0; A.inv_dz = c->P.dz > 0 ? 1.0 / c->P.dz : 0.0;
     return A;
+}
+
+hipError_t amc_launch_commit(amc_ctx *c)
+{
+    rs_args A = rs_make_args(c);
+    A.defer_commit = c->commit_defer ? 1 : 0;
+    amc_prof_begin(c, AMC_K_COMMIT);
+    hipLaunchKernelGGL(k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), 0, c->stream, A);
+    amc_prof_end(c);
+    return hipGetLastError();
 }
 
 hipError_t amc_launch_apply(amc_ctx *c)

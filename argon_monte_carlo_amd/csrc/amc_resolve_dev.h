@@ -298,20 +298,11 @@ AMC_DEV int rs_next_common(double v1, double v2, double d, double inv_d, double 
 }
 
 // ---- two-particle cluster: literal emulation with both particles in registers -----------------------------------------
-AMC_DEV amc_particle rs_load_cst(const amc_resolve_ws &W, int k, int which)
-{
-    const double *t = W.cst + (size_t)k * RS_CST_DOUBLES + 11 * which;      // one 192-byte record per candidate
-    amc_particle q;
-    q.x = t[0]; q.y = t[1]; q.z = t[2]; q.vx = t[3]; q.vy = t[4]; q.vz = t[5];
-    q.d = t[6]; q.dx = t[7]; q.dy = t[8]; q.dz = t[9]; q.flag = t[10] != 0.0;
-    return q;
-}
-
 template <int GEOM>
-AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, int k, int pj, int pi, int sj, int si, rs_wide *wd = nullptr)
+AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, amc_particle p2, int pj, int pi, int sj, int si,
+                             rs_wide *wd = nullptr)
 {
     const amc_params &P = A.P;
-    amc_particle p1 = rs_load_cst(A.W, k, 0), p2 = rs_load_cst(A.W, k, 1);   // coalesced rows gathered by detect
     bool moved = false;
     const double cr = P.collision_range;
     if (GEOM == AMC_GEOM_CELL) {

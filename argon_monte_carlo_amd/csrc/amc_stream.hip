@@ -10,13 +10,18 @@
 // (Pore:442-485) — which is exactly a per-particle sequential evaluation.
 #include <string.h>
 
-#include "amc_grid_dev.h"
+#include "amc_commit_dev.h"
 
 template <int GEOM>
 __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_out O, double dt, int stages,
                                                 long long lo, long long hi, int keep_prior, int bounds_slot,
-                                                amc_grid G, amc_lists B, int build_lists, amc_lazy L)
+                                                amc_grid G, amc_lists B, int build_lists, amc_lazy L, amc_commit_args C)
 {
+    // the previous sweep's commit rides along on the first blocks (amc_commit_dev.h): order-free work that nothing in this
+    // pass depends on (results reach the particles through slot_of[] below)
+    if (C.enabled && blockIdx.x < AMC_COMMIT_BLOCKS)
+        amc_commit_part(C, O, G, S, (int)(blockIdx.x * blockDim.x + threadIdx.x),
+                        (int)((gridDim.x < AMC_COMMIT_BLOCKS ? gridDim.x : AMC_COMMIT_BLOCKS) * blockDim.x));
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
     amc_particle q;
@@ -143,6 +148,17 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
     if (noob_pre) atomicAdd(&O.cnt->n_oob_pp, (unsigned long long)noob_pre);
 }
 
+amc_commit_args amc_make_commit_args(amc_ctx *c)
+{
+    const amc_resolve_ws &W = c->W;
+    amc_commit_args C;
+    C.ctl = (amc_resolve_ctl *)W.ctl; C.hist = W.hist; C.ov_head = W.ov_head; C.ev_gen = W.ev_gen; C.ev = W.ev;
+    C.sl_meta = W.sl_meta; C.sl_hits = W.sl_hits; C.sl_moved = W.sl_moved; C.sl_state = W.sl_state; C.slot_of = W.slot_of;
+    C.max_slots = W.max_slots; C.max_hist = W.max_hist; C.lo = c->lo; C.hi = c->hi; C.count_pp = c->mg_count_pp ? 1 : 0;
+    C.defer = c->commit_defer ? 1 : 0; C.nogrid = c->allpairs ? 1 : 0; C.enabled = 0;
+    return C;
+}
+
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin)
 {
     int build = 0;
@@ -157,6 +173,8 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     }
     const long long cnt = c->hi - c->lo;
     if (cnt <= 0) return hipSuccess;
+    amc_commit_args C = amc_make_commit_args(c);
+    if (c->commit_pending) { C.enabled = 1; c->commit_pending = false; }   // this pass does the last sweep's commit as well
     const int threads = 256;
     const unsigned blocks = (unsigned)((cnt + threads - 1) / threads);
     const int kp = c->keep_prior ? 1 : 0;
@@ -164,15 +182,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     case AMC_GEOM_PORE:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
-                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
+                           stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     case AMC_GEOM_PORE_ENERGISED:
         hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
-                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L);
+                           c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     default:
         break;

@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--device-rng", action="store_true",
                     help="temp workloads: opt-in NON-PARITY mode, re-emission directions / gap energies drawn on the GPU (Philox)")
     ap.add_argument("--force-sharded", action="store_true", help="rehearsal: run the sharded driver (and its collectives) even with one rank")
+    ap.add_argument("--strong", action="store_true", help="N>1: keep the TOTAL particle count at the workload's size (strong scaling) instead of the per-GPU count")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -253,7 +254,7 @@ def main():
         from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
         from argon_monte_carlo_amd.engine import EnergisedEngine
         sharded = world > 1 or args.force_sharded
-        n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
+        n_total = n_per_gpu if args.strong else n_per_gpu * world       # weak scaling (default): per-GPU particles fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
         p.reserved0 |= 1
         p.E_cold, p.E_hot = SurfaceEnergies(c).cold, SurfaceEnergies(c).hot          # Temp:83-84
@@ -283,7 +284,7 @@ def main():
                 tot = st if tot is None else {kk: tot[kk] + st[kk] for kk in st}
             return tot
         parallelism = ("single GPU" if not sharded else f"index-range shards x{world}, hits concatenated in index order, "
-                       "one all-gather per step: positions + changed velocities (RCCL)") + \
+                       "one all-gather per step: positions + changed velocities (RCCL), list build + p-p sweep replicated on every rank") + \
             (" + device-side Philox sampling (opt-in, NOT the reference's random streams)" if args.device_rng else
              " + host RNG/mpmath hand-over per energised case")
         engines = [eng.engine if sharded else eng]
@@ -312,13 +313,15 @@ def main():
         engines = [eng]
     else:
         from argon_monte_carlo_amd.dist import ShardedSimulation
-        n_total = n_per_gpu * world                     # weak scaling: per-GPU work fixed
+        n_total = n_per_gpu if args.strong else n_per_gpu * world       # weak scaling (default): per-GPU particles fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
         sim = ShardedSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
         driver = sim
         sim.upload(*init)
         step = lambda k: sim.run(c["dt"], k)          # noqa: E731
-        parallelism = f"index-range shards x{world}, one all-gather per step: positions + changed velocities (RCCL)"
+        parallelism = (f"index-range shards x{world}: streaming pass (drift, walls, bounds) on the shard, one all-gather per step "
+                       "(positions + changed velocities, RCCL), then list build + p-p sweep of the WHOLE system REPLICATED on "
+                       "every rank (per-rank sweep time grows with the total particle count; DESIGN.md 6)")
         engines = [sim.engine]
 
     def sync():
@@ -399,7 +402,7 @@ def main():
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if (args.strong and world > 1) else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "geometry": kind, "n_particles": n_total, "n_per_gpu": n_local,
                        "dt": c["dt"], "parallelism": parallelism,
                        "pp_collisions_per_step": stats["n_pp"] / args.steps if stats else None},

@@ -784,8 +784,9 @@ def test_tolerated_fp_events_match_oracle(Engine, O):
 @pytest.mark.parametrize("kind,n", [("cube", 400_000), ("pore", 1_000_000)])
 def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
     """Every sweep emulates its small clusters in the wide kernel (k_clusters_wide, validation included) and leaves the
-    entangled rest to the ordered workgroup; sweeps with many candidates are committed by the wide commit kernel.  State
-    and counters equal the oracle's bit for bit at every step, and the profile shows that both wide kernels ran."""
+    entangled rest to the ordered workgroup; the commit rides along with the next streaming pass (pore: the bounds check
+    after the sweep) or runs as k_commit when the counters are read first (cube).  State and counters equal the oracle's
+    bit for bit at every step, and the profile shows that the wide kernel ran in every sweep."""
     if kind == "cube":
         p, c = PR.cube_params_for_n(n)
         init = IC.cube_ic(p, c, seed=127)
@@ -810,7 +811,8 @@ def test_large_sweep_plan_with_wide_pair_kernel_vs_oracle(Engine, O, kind, n):
     kt = eng.kernel_times()
     eng.profile(False)
     assert ncand > 640
-    assert kt["clusters_wide"][1] >= 6 and kt["commit"][1] >= 4, kt
+    assert kt["clusters_wide"][1] >= 6 and kt["resolve"][1] >= 6, kt
+    assert kt["commit"][1] >= (4 if kind == "cube" else 0), kt
     eng.close()
 
 
