@@ -756,9 +756,10 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
                 h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[14] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
                 h[8] / n, h[9] / n, h[10] / n, h[11]);
         const double w = h[31] > 0 ? (double)h[31] : 1.0;
-        fprintf(stderr, "[amc k_clusters_wide phases, us per working wave] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f | waves %lld | launch span (first wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us\n",
+        fprintf(stderr, "[amc k_clusters_wide phases, us per working wave] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f | waves %lld | launch span (first wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us; launches with a re-emulation: %lld, their span %.2f us, the others' %.2f us\n",
                 h[16] / w / 100.0, h[17] / w / 100.0, h[18] / w / 100.0, h[19] / w / 100.0, h[20] / w / 100.0, h[21] / w / 100.0, h[22] / w / 100.0, h[31],
-                h[27] / n / 100.0, h[26] / n / 100.0, h[30] / 100.0);
+                h[27] / n / 100.0, h[26] / n / 100.0, h[30] / 100.0, h[25], h[25] ? h[23] / (double)h[25] / 100.0 : 0.0,
+                (n - h[25]) > 0 ? (h[27] - h[23]) / (n - h[25]) / 100.0 : 0.0);
     }
     for (int k = 0; k < AMC_K_COUNT; k++) {
         if (total_ms) total_ms[k] = c->k_ms[k];

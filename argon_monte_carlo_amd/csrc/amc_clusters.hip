@@ -290,13 +290,13 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                     bool seen = false;
                     for (int e = 0; e < nc; e++) seen |= cnd[e] == c;
                     if (!seen) {
-                        if (nc == CW_MAXC) { owner = false; break; }       // too large for this kernel
+                        if (nc == CW_MAXC) { owner = false; wc->changed = 1; break; }       // too large for this kernel: left to the ordered workgroup
                         cnd[nc++] = c;
                     }
                     seen = false;
                     for (int e = 0; e < nm; e++) seen |= mem[e] == q;
                     if (!seen) {
-                        if (nm == CW_MAXM) { owner = false; break; }
+                        if (nm == CW_MAXM) { owner = false; wc->changed = 1; break; }
                         mem[nm++] = q;
                     }
                     c = nx;
@@ -320,11 +320,9 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
         L.redo[lane] = take ? 1 : 0;
         L.gen[lane] = 0;
         {
+            // statistics: one counter per bank of waves (2000 waves adding to ONE word are a 24 us chain of same-address atomics)
             const int ncl = __popcll(__ballot(take));
-            int ndone = iso ? 1 : (owner ? nc : 0);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ndone += __shfl_xor(ndone, o, 64);
-            if (lane == 0 && ncl) { atomicAdd(&wc->nclusters, ncl); atomicAdd(&wc->changed, ndone); }
+            if (lane == 0 && ncl) atomicAdd(&W.wctl[32 + (blockIdx.x & 15)], ncl);
         }
         __syncthreads();
         CW_STAMP(2);
@@ -447,6 +445,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
             // a cluster that pulled particles in is emulated again from the untouched pre-sweep state, unless it has had
             // its turns: then the particles still get their slots and the ordered workgroup takes over
             if (!__syncthreads_or(L.redo[lane])) break;
+            if (A.dbg && lane == 0) A.dbg[24] = 1;          // (diagnostic: this launch has a wave that emulates again)
             if (iter + 1 == CW_ITERS || L.nitems >= CW_ITEMS - 8) {
                 if (L.redo[lane]) {
                     const int np = L.npull[lane] < CW_PULLS ? L.npull[lane] : CW_PULLS;

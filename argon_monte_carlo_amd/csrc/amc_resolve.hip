@@ -56,7 +56,9 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
     if (A.dbg && threadIdx.x == 0 && MODE == 0 && A.dbg[29] > 0) {      // span of the wide kernel's launch (first wave in -> last wave out)
-        A.dbg[27] += A.dbg[29] - A.dbg[28]; A.dbg[26] += t_last - A.dbg[29]; A.dbg[28] = 0x7fffffffffffffffLL; A.dbg[29] = 0;
+        A.dbg[27] += A.dbg[29] - A.dbg[28]; A.dbg[26] += t_last - A.dbg[29];
+        if (A.dbg[24]) { A.dbg[23] += A.dbg[29] - A.dbg[28]; A.dbg[25] += 1; A.dbg[24] = 0; }
+        A.dbg[28] = 0x7fffffffffffffffLL; A.dbg[29] = 0;
     }
     __shared__ rs_shared sh;
     __shared__ int wide_ns;             // slots made by the wide cluster kernel in this sweep, -1 if it did not run
@@ -88,11 +90,13 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
             rs_shared *wc = (rs_shared *)W.wctl;
             const int off = 2 * ncand;
             sh.nslots = off + wc->nslots < W.max_slots ? off + wc->nslots : W.max_slots;
-            sh.nhist = off + wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges; sh.nclusters = wc->nclusters;
+            sh.nhist = off + wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges;
+            sh.nclusters = 0;
+            for (int b = 0; b < 16; b++) { sh.nclusters += W.wctl[32 + b]; W.wctl[32 + b] = 0; }      // (banked by the wide kernel's waves)
             wide_dirty = wc->dirty;
             wide_ns = wc->active ? sh.nslots : -1;              // (>= 0: the wide kernel ran, W.cand_s[k].z is valid)
             wide_nh = sh.nhist < W.max_hist ? sh.nhist : W.max_hist;
-            s_left = ncand - wc->changed;                       // candidates it did not take (components too large for it)
+            s_left = wc->changed ? -1 : 0;                      // it left components too large for it (how many candidates: counted below)
             wc->nslots = 0; wc->nhist = 0; wc->nedges = 0; wc->nfp = 0; wc->ovf = 0; wc->dirty = 0; wc->nclusters = 0;
             wc->changed = 0; wc->active = 0; wc->cur_round = 1;
             if (wide_ns < 0) { sh.nslots = 0; sh.nhist = 0; s_left = ncand; }        // (it did not run)
@@ -115,6 +119,15 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
     const int gen_off = wide ? 16 : 0;          // (the wide kernel tags its own re-emulations of a cluster with rounds 1, 2, 3)
     const bool mono = (MODE == 2);      // commit in this kernel (no-grid mode); with a grid the commit is wide work of its own:
                                         // it rides along with the next streaming pass or runs as k_commit
+    if (s_left < 0) {                   // (rare: the wide kernel met a component beyond its capacity)
+        __syncthreads();
+        if (tid == 0) s_left = 0;
+        __syncthreads();
+        int mine = 0;
+        for (int k = tid; k < ncand; k += RS_T) mine += !W.cand_s[k].z;
+        if (mine) atomicAdd(&s_left, mine);
+        __syncthreads();
+    }
     const int nleft = s_left;
     // nothing left and nothing found by the wide kernel's validation: the sweep is resolved, only the commit remains
     const bool resolved = wide && nleft == 0 && !wide_dirty;
