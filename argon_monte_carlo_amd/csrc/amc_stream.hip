@@ -10,6 +10,8 @@
 // (Pore:442-485) — which is exactly a per-particle sequential evaluation.
 #include <string.h>
 
+#include <algorithm>
+
 #include "amc_commit_dev.h"
 
 template <int GEOM>
@@ -17,11 +19,15 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_params P, amc_o
                                                 long long lo, long long hi, int keep_prior, int bounds_slot,
                                                 amc_grid G, amc_lists B, int build_lists, amc_lazy L, amc_commit_args C)
 {
-    // the previous sweep's commit rides along on the first blocks (amc_commit_dev.h): order-free work that nothing in this
-    // pass depends on (results reach the particles through slot_of[] below)
-    if (C.enabled && blockIdx.x < AMC_COMMIT_BLOCKS)
-        amc_commit_part(C, O, G, S, (int)(blockIdx.x * blockDim.x + threadIdx.x),
-                        (int)((gridDim.x < AMC_COMMIT_BLOCKS ? gridDim.x : AMC_COMMIT_BLOCKS) * blockDim.x));
+    // the previous sweep's commit rides along on EXTRA blocks behind the streaming ones (amc_commit_dev.h): order-free work
+    // that nothing in this pass depends on (results reach the particles through slot_of[] below), done while the others stream
+    if (C.enabled) {
+        const unsigned nstream = gridDim.x - (unsigned)C.enabled;       // (enabled = number of commit blocks)
+        if (blockIdx.x >= nstream) {
+            amc_commit_part(C, O, G, S, (int)((blockIdx.x - nstream) * blockDim.x + threadIdx.x), (int)(C.enabled * blockDim.x));
+            return;
+        }
+    }
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
     amc_particle q;
@@ -174,9 +180,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     const long long cnt = c->hi - c->lo;
     if (cnt <= 0) return hipSuccess;
     amc_commit_args C = amc_make_commit_args(c);
-    if (c->commit_pending) { C.enabled = 1; c->commit_pending = false; }   // this pass does the last sweep's commit as well
+    unsigned extra = 0;
+    if (c->commit_pending) {            // this launch does the last sweep's commit as well, on blocks of its own
+        const long long lag = c->h_host_ncand ? *c->h_host_ncand : 0;      // (entries to commit ~ 2 per candidate)
+        extra = (unsigned)std::min<long long>(std::max<long long>((2 * lag + 255) / 256, 4), AMC_COMMIT_BLOCKS);
+        C.enabled = (int)extra;
+        c->commit_pending = false;
+    }
     const int threads = 256;
-    const unsigned blocks = (unsigned)((cnt + threads - 1) / threads);
+    const unsigned blocks = (unsigned)((cnt + threads - 1) / threads) + extra;
     const int kp = c->keep_prior ? 1 : 0;
     amc_prof_begin(c, (stages == AMC_ST_BOUNDS) ? AMC_K_BOUNDS : AMC_K_DRIFT_WALLS);
     switch (c->P.geometry) {
