@@ -79,13 +79,6 @@ struct amc_resolve_ws {
     int *sl_hits;             // collisions (low half) and failed contact solves (high half) counted on the slot: atomics only
     uint8_t *sl_moved;        // the slot's scratch state differs from the particle arrays
     double *sl_state;         // [max_slots][RS_SLOT_DOUBLES]
-    int *sl_label, *sl_tmp;   // labels / sizes of the ordered workgroup when they do not fit its LDS
-    uint8_t *sl_dirty;
-    unsigned long long *sl_key;                    // sort keys (label<<32 | particle)
-    int *order;
-    double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
-    int *cw_tmp, *cw_pidx, *cw_slot;
-    uint8_t *cw_flag, *cw_moved;
     int *edge_a, *edge_b;     // merge edges found by validation (particles, or slots encoded as -(slot + 2))
     int max_edges;
     double4 *hist;            // position history of the sweep: (x, y, z, slot | round << 32) per new position
@@ -97,6 +90,14 @@ struct amc_resolve_ws {
     rs_event *ev;             // [max_hist]
     int *ctl;                 // rs_shared in global memory: hand-over between the resolve kernels
     int *wctl;                // rs_shared of the wide cluster kernel (counters it advanced before the ordered workgroup starts)
+    // (what only the ordered workgroup's large-sweep fallbacks touch comes last: the argument block is read line by line)
+    int *sl_label, *sl_tmp;   // labels / sizes of the ordered workgroup when they do not fit its LDS
+    uint8_t *sl_dirty;
+    unsigned long long *sl_key;                    // sort keys (label<<32 | particle)
+    int *order;
+    double *cw_d[10];         // global fallback of the multi-particle clusters' working set (else LDS)
+    int *cw_tmp, *cw_pidx, *cw_slot;
+    uint8_t *cw_flag, *cw_moved;
 };
 
 // energised-wall hand-over buffers (amc_energised.hip)

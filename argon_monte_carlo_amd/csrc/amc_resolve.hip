@@ -554,7 +554,10 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
 static rs_args rs_make_args(amc_ctx *c)
 {
     rs_args A;
-    A.P = c->P; A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
+    A.P.collision_range = c->P.collision_range; A.P.argon_mass = c->P.argon_mass; A.P.dx = c->P.dx; A.P.dy = c->P.dy; A.P.dz = c->P.dz;
+    A.P.overlap_x = c->P.overlap_x; A.P.overlap_y = c->P.overlap_y; A.P.overlap_z = c->P.overlap_z;
+    A.P.nx = c->P.nx; A.P.ny = c->P.ny; A.P.nz = c->P.nz; A.P.geometry = c->P.geometry;
+    A.S = c->S; A.G = c->G; A.B = c->B; A.W = c->W; A.O = c->out; A.n = c->n; A.allpairs = c->allpairs ? 1 : 0;
     A.dbg = c->d_dbg;
     A.force_mono = 0;
     A.host_ncand = c->d_host_ncand;

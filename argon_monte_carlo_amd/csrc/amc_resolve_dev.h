@@ -10,11 +10,18 @@
 #define RS_MAX_ROUNDS 256
 #define AMC_CR2_INFLATE (1.0 + 1.0e-9)
 
+// what the resolve kernels need of amc_params (the whole structure is 416 bytes, seven cache lines of kernel arguments that
+// a lone wave would fetch one dependent scalar load after the other)
+struct rs_geom {
+    double collision_range, argon_mass, dx, dy, dz, overlap_x, overlap_y, overlap_z;
+    int nx, ny, nz, geometry;
+};
+
 struct rs_args {
-    amc_params P;
+    rs_geom P;
     amc_state S;
-    amc_grid G;
     amc_lists B;
+    amc_grid G;
     amc_resolve_ws W;
     amc_out O;
     long long n;
@@ -223,7 +230,7 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     return !fail;
 }
 
-AMC_DEV int rs_pore_cell(const amc_params &P, double x, double y, double z, int gx, int gy, int gz)
+AMC_DEV int rs_pore_cell(const rs_geom &P, double x, double y, double z, int gx, int gy, int gz)
 {
     const int lx = amc_axis_cell(x, gx, P.nx, P.nx, P.dx, P.overlap_x);
     if (lx < 0) return -1;
@@ -249,7 +256,7 @@ AMC_DEV void rs_axis_k(double v, double d, double inv_d, double ov, int &ka, int
 }
 AMC_DEV void rs_pore_ks(const rs_args &A, const amc_particle &q, int *k)
 {
-    const amc_params &P = A.P;
+    const rs_geom &P = A.P;
     rs_axis_k(q.x, P.dx, A.inv_dx, P.overlap_x, k[0], k[1]);
     rs_axis_k(q.y, P.dy, A.inv_dy, P.overlap_y, k[2], k[3]);
     rs_axis_k(q.z, P.dz, A.inv_dz, P.overlap_z, k[4], k[5]);
@@ -267,7 +274,7 @@ AMC_DEV int rs_layer_from_k(int ka, int kb, int grp, int nlayers, int offset)
     }
     return -1;
 }
-AMC_DEV int rs_pore_cell_k(const amc_params &P, const int *k, int g)
+AMC_DEV int rs_pore_cell_k(const rs_geom &P, const int *k, int g)
 {
     const int lx = rs_layer_from_k(k[0], k[1], g >> 2, P.nx, P.nx);
     if (lx < 0) return -1;
@@ -302,7 +309,7 @@ template <int GEOM>
 AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, amc_particle p2, int pj, int pi, int sj, int si,
                              rs_wide *wd = nullptr)
 {
-    const amc_params &P = A.P;
+    const rs_geom &P = A.P;
     bool moved = false;
     const double cr = P.collision_range;
     if (GEOM == AMC_GEOM_CELL) {
@@ -391,7 +398,7 @@ template <int GEOM, int M>
 AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)[M], const int (&pidx)[M],
                               const int (&slot)[M], bool (&moved)[M], rs_wide *wd)
 {
-    const amc_params &P = A.P;
+    const rs_geom &P = A.P;
     const double cr = P.collision_range;
     bool ovp[M][M];                     // ovp[c][a], c < a: the pair overlaps at the current positions
     bool any = false;
@@ -517,7 +524,7 @@ AMC_DEV int rs_next_layer(const rs_work &K, int b, int e, const double *v, int n
 
 AMC_DEV void rs_emulate_generic(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e, rs_wide *wd = nullptr)
 {
-    const amc_params &P = A.P;
+    const rs_geom &P = A.P;
     if (P.geometry == AMC_GEOM_CELL) {
         for (int a = b + 1; a < e; a++)                                                     // Pore:168-169
             for (int c = b; c < a; c++) rs_test_work(A, sh, K, c, a, 16, 0, wd);
@@ -686,7 +693,7 @@ AMC_DEV int rs_next_layer_coop(const rs_work &K, int b, int pa, int pc, const do
 
 AMC_DEV void rs_emulate_coop(const rs_args &A, rs_shared *sh, const rs_work &K, int b, int e, rs_wide *wd = nullptr)
 {
-    const amc_params &P = A.P;
+    const rs_geom &P = A.P;
     const int lane = threadIdx.x & 63, m = e - b;
     const int w = b + lane;                 // my member (lanes < m)
     int pa, pc;

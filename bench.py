@@ -74,6 +74,25 @@ def make_workload(name, n_override=None, device=0):
     return p, c, init
 
 
+def host_cores():
+    """Host cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one.  A GPU box
+    shows all of its (hundreds of) cores to a job that owns a share of them: without a visible limit the count is capped at
+    16, the share that goes with one GPU on the measurement boxes (AMC_BENCH_CORES overrides)."""
+    if os.environ.get("AMC_BENCH_CORES"):
+        return max(1, int(os.environ["AMC_BENCH_CORES"]))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n if n <= 64 else 16
+
+
 def cpu_baseline(workload, budget_s=12.0):
     """The oracle (oracle/amc_oracle.c, `mul` variant) on the host, on a bounded number of steps of the SAME workload.
     Reported next to the GPU number; it is a baseline, not the target.  Three figures:
@@ -86,7 +105,7 @@ def cpu_baseline(workload, budget_s=12.0):
     from oracle import oracle as O
     p, c, init = make_workload(workload)
     kind = WORKLOADS[workload][0]
-    ncores = os.cpu_count() or 1
+    ncores = host_cores()
 
     def timed(one, budget):
         one()                                       # warm-up (page faults)
@@ -137,15 +156,16 @@ def cpu_baseline_python_mp(n=100_000, steps=3):
     from oracle import pymp_structure as PM
     p, c = PR.pore_params(n=n)
     init = IC.pore_ic(p, c, seed=17)
-    s = PM.PyMpStepper(p)
+    ncores = host_cores()
+    s = PM.PyMpStepper(p, workers=ncores + 1)           # the reference's Pool(cpu_count() + 1) on the cores this job has
     s.upload(*init)
     t0 = time.perf_counter()
     npp = 0
     for _ in range(steps):
         npp += s.timestep(c["dt"])["n_pp"]
     el = time.perf_counter() - t0
-    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "workers": (os.cpu_count() or 1) + 1,
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
+            "workers": ncores + 1,
             "sample": f"{steps} steps (no warm-up) of the specular pore at N={n} in {el:.1f} s, {npp} p-p collisions; "
                       "oracle/pymp_structure.py (NumPy-scalar pair loop, full per-cell boolean masks, fresh Pool per colour group)"}
 
@@ -162,6 +182,8 @@ def committed_traffic(workload, kclass, tag):
     kern = json.load(open(path)).get("kernels", {})
     for name, v in kern.items():
         if needle and needle in name and (kclass != "resolve" or name.rstrip().endswith("0>")) and "bounds-only" not in name:
+            if "HBM_bytes_corrected" in v:
+                return float(v["HBM_bytes_corrected"]), f"profiles/{os.path.basename(path)}: {name} ({v.get('correction', '')})"
             kib = v.get("FETCH_SIZE_KiB_avg", 0.0) + v.get("WRITE_SIZE_KiB_avg", 0.0)
             return kib * 1024.0, f"profiles/{os.path.basename(path)}: {name} (FETCH_SIZE + WRITE_SIZE, uncorrected)"
     return None, None

@@ -106,7 +106,8 @@ typedef struct amc_params {
     /* engine knobs (not physics) */
     double fine_cell;             /* edge of the detection grid cells (m); 0 = choose automatically     */
     int32_t device;               /* HIP device ordinal                                                */
-    int32_t detect_mode;          /* 0 auto, 1 binned (cell grid), 2 tiled all-pairs                   */
+    int32_t detect_mode;          /* 0 auto, 1 binned (cell grid), 2 tiled all-pairs detector (no grid at
+                                   * all up to 4096 particles; above, in front of the grid-based resolve) */
     int64_t max_candidates;       /* capacity of the candidate-pair list; 0 = default                  */
     int64_t max_paths;            /* capacity of the completed-path record buffer; 0 = default (2^20), < 0 = no
                                    * records at all (completed paths only go into the device histograms)     */
@@ -312,11 +313,11 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 #define AMC_K_BIN_SCAN 2         /* reserved (no such pass: the lists need neither scan nor scatter) */
 #define AMC_K_BIN_SCATTER 3      /* reserved */
 #define AMC_K_DETECT 4
-#define AMC_K_RESOLVE 5          /* k_resolve: the ordered workgroup (entangled remainder, later rounds, commit of a small sweep) */
+#define AMC_K_RESOLVE 5          /* k_resolve: the ordered workgroup (entangled remainder, later rounds; no-grid mode: everything) */
 #define AMC_K_BOUNDS 6
 #define AMC_K_VALIDATE 7         /* reserved (validation happens inside k_clusters_wide / k_resolve)            */
 #define AMC_K_RESOLVE_MORE 8     /* reserved (later rounds run inside k_resolve)                                */
-#define AMC_K_COMMIT 9           /* k_commit: wide commit of a large sweep                                      */
+#define AMC_K_COMMIT 9           /* k_commit: a sweep's commit as a launch of its own (else it rides along with the next k_stream) */
 #define AMC_K_CLUSTERS_WIDE 10   /* k_clusters_wide: every small cluster emulated and validated wide, before the ordered workgroup */
 #define AMC_K_COUNT 12
 int amc_profile(amc_ctx *ctx, int enable);

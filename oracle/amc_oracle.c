@@ -62,6 +62,20 @@ static void orc_emit(orc_sink *s, int32_t step, int32_t phase, int64_t cell, int
 #undef ORC
 #undef SQ
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads of the *_par functions (libgomp reads OMP_NUM_THREADS when it is loaded: too early for a caller that finds
+ * out its CPU share at run time) */
+void orc_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_abi_version(void) { return AMC_ABI_VERSION; }
 int64_t orc_sizeof_params(void) { return (int64_t)sizeof(amc_params); }
 int64_t orc_sizeof_path_record(void) { return (int64_t)sizeof(amc_path_record); }

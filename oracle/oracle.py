@@ -111,7 +111,7 @@ class Oracle:
         counted, not recorded.  For the pore the state equals timestep()'s; for the cube the colouring is NOT the
         reference's serial order (see amc_oracle_impl.h)."""
         if threads:
-            os.environ["OMP_NUM_THREADS"] = str(int(threads))
+            self.L.orc_set_threads(C.c_int(int(threads)))
         st = AmcStepStats()
         rc = self._fn("timestep_par")(C.byref(self.p), C.byref(self._state), C.c_double(dt), C.byref(st))
         self.step += 1
