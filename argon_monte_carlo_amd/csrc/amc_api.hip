@@ -159,8 +159,7 @@ void amc_destroy(amc_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz, c->S.px, c->S.py,
-                    c->S.pz, c->S.flag, c->d_lay, c->B.rec, c->B.head, c->W.ov_head, c->w_slab, c->d_rec, c->d_hist,
+    void *ptrs[] = {c->s_slab, c->d_lay, c->B.rec, c->B.head, c->W.ov_head, c->w_slab, c->d_rec, c->d_hist,
                     c->d_edges, c->d_cnt, c->d_banks, c->d_dbg};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -212,7 +211,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pin = nullptr;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
-    c->d_dbg = nullptr; c->w_slab = nullptr;
+    c->d_dbg = nullptr; c->w_slab = nullptr; c->s_slab = nullptr;
     c->mg_count_pp = true;
     c->lazy_pending = false; c->commit_pending = false; c->commit_defer = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;
@@ -248,9 +247,17 @@ int amc_create(amc_ctx **out, const amc_params *p)
         }
         double **st[] = {&c->S.x, &c->S.y, &c->S.z, &c->S.vx, &c->S.vy, &c->S.vz, &c->S.d, &c->S.dx, &c->S.dy, &c->S.dz,
                          &c->S.px, &c->S.py, &c->S.pz};
-        for (auto pp : st) { CK(dalloc(pp, n)); CK(hipMemsetAsync(*pp, 0, sizeof(double) * std::max<size_t>(n, 1), c->stream)); }
-        CK(dalloc(&c->S.flag, n));
-        CK(hipMemsetAsync(c->S.flag, 0, std::max<size_t>(n, 1), c->stream));
+        {
+            // the particle state in ONE allocation: the resolve kernels gather the eleven fields of a particle from eleven
+            // arrays — in one slab they share address-translation entries instead of needing one each
+            const size_t per = ((sizeof(double) * std::max<size_t>(n, 1)) + 255) & ~(size_t)255;
+            const size_t total = 13 * per + ((std::max<size_t>(n, 1) + 255) & ~(size_t)255);
+            CK(hipMalloc((void **)&c->s_slab, total));
+            CK(hipMemsetAsync(c->s_slab, 0, total, c->stream));
+            size_t off = 0;
+            for (auto pp : st) { *pp = (double *)(c->s_slab + off); off += per; }
+            c->S.flag = (uint8_t *)(c->s_slab + off);
+        }
         if ((rc = setup_grid(c)) != AMC_OK) goto fail;
         if (!c->allpairs) {
             const size_t nc = (size_t)c->G.ncells;

@@ -46,7 +46,7 @@ AMC_DEV int cw_adj_head(const amc_resolve_ws &W, unsigned int epoch, int p)
 #define CW_ITERS 3          // emulations of one cluster in this kernel: the first + two after it pulled particles in
 #define CW_PULLS 4          // particles one cluster can pull in per validation
 
-AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label, int gen)
+AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label, int gen, bool fresh = false)
 {
     W.slot_of[p] = s; W.sl_moved[s] = 0;
     // (particle, label, round, -) written through: a prober of another workgroup that meets one of this slot's history
@@ -54,7 +54,8 @@ AMC_DEV void cw_init_slot(const amc_resolve_ws &W, int s, int p, int label, int 
     unsigned long long *m = (unsigned long long *)&W.sl_meta[s];
     __hip_atomic_store(m + 0, ((unsigned long long)(unsigned int)label << 32) | (unsigned int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(m + 1, (unsigned long long)(unsigned int)gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicAnd(&W.sl_hits[s], 0);        // (an atomic, like the increments that follow)
+    if (!fresh) atomicAnd(&W.sl_hits[s], 0);    // (an atomic, like the increments that follow; a candidate's own slot was
+                                                // zeroed by the detect kernel when it pushed the candidate)
 }
 
 AMC_DEV double4 cw_load_hist(const amc_resolve_ws &W, int h)
@@ -219,8 +220,9 @@ AMC_DEV void cw_candidate_slots(const amc_resolve_ws &W, cw_lds &L, int own, int
 }
 
 template <int GEOM>
-__global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
+__global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
 {
+    RS_STAGE_ARGS(A);
     const amc_resolve_ws &W = A.W;
     rs_shared *wc = (rs_shared *)W.wctl;
     __shared__ cw_lds L;
@@ -339,8 +341,8 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A)
                 if (my_m == 2) {
                     // (an isolated pair; only ever emulated once: a pair that pulls a particle in comes back as three)
                     const int pj = mem[0], pi = mem[1], sj = L.msl[lane][0], si = L.msl[lane][1];
-                    cw_init_slot(W, sj, pj, lab, g + 1);
-                    cw_init_slot(W, si, pi, lab, g + 1);
+                    cw_init_slot(W, sj, pj, lab, g + 1, true);
+                    cw_init_slot(W, si, pi, lab, g + 1, true);
                     W.cand_s[k] = make_int4(si, sj, 1, 0);
                     rs_emulate_pair<GEOM>(A, wc, pre_j, pre_i, pj, pi, sj, si, &wd);
                 } else {

@@ -144,6 +144,7 @@ struct amc_ctx {
     amc_lists B;
     amc_resolve_ws W;
     char *w_slab;             // the one allocation W's arrays are carved from
+    char *s_slab;             // the one allocation the particle state arrays are carved from
     amc_temp_ws T;
     amc_temp_dev_ws TD;
     bool allpairs;            // no detection grid at all (single cells, N <= 4096): all-pairs detector, brute-force validation
