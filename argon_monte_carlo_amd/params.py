@@ -2,7 +2,7 @@
 
 Every value below is computed in the same order of operations as the line it cites (Cube = Open_Air_Cube_MC.py,
 Pore = Open_Air_Pore_MC.py, Temp = Temperature_Pore_MC.py under /root/reference) so that the resulting doubles are
-bit-identical to the reference's module constants (checked in tests/test_params.py against values captured from the
+bit-identical to the reference's module constants (checked in tests/test_host.py against values captured from the
 imported reference).  The result is an ``AmcParams`` (ctypes mirror of ``amc_params``, include/argonmc.h).
 """
 from __future__ import annotations

@@ -58,9 +58,26 @@ def main():
     procs = [ctx.Process(target=worker, args=(r, world, port, workload, steps, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    full, tot, counts, npaths, el = q.get(timeout=900)
-    for pr in procs:
-        pr.join(timeout=120)
+    import queue
+    try:
+        t0 = time.time()
+        while True:                                 # a rank that dies ends the run at once (its peers hold GPU contexts)
+            try:
+                full, tot, counts, npaths, el = q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                if any(pr.exitcode not in (None, 0) for pr in procs) or time.time() - t0 > 900:
+                    raise SystemExit("a rank died or the run timed out")
+        for pr in procs:
+            pr.join(timeout=120)
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.terminate()
+        for pr in procs:
+            pr.join(timeout=10)
+            if pr.is_alive():
+                pr.kill()
     first_bad = next((k for k in KEYS if not np.array_equal(full[k], ref[k])), None)
     ckeys = ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors")
     out = {"workload": workload, "n": int(p.n), "steps": steps, "ranks_on_one_gpu": world, "collectives": "gloo, staged through the host",

@@ -158,6 +158,36 @@ def _worker(rank, world, port, n, steps, q):
         dist.destroy_process_group()
 
 
+def _first_result(q, procs, timeout):
+    """Rank 0's result, or a failure as soon as a rank has died; no child outlives the call."""
+    import queue
+    import time
+    try:
+        t0 = time.time()
+        while True:
+            try:
+                out = q.get(timeout=1.0)
+                break
+            except queue.Empty:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                if dead:
+                    pytest.fail(f"a rank exited with code {dead[0].exitcode}")
+                if time.time() - t0 > timeout:
+                    pytest.fail(f"no result after {timeout} s")
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return out
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -185,10 +215,7 @@ def test_ranks_equal_one_rank(n, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got, tot = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got, tot = _first_result(q, procs, 120)
     assert ref_tot["n_candidates"] > 0
     for k in KEYS:
         a, b = got[k], ref[k]
@@ -258,10 +285,7 @@ def test_energised_walls_two_ranks_equal_one_rank():
     procs = [ctx.Process(target=_temp_worker, args=(r, 2, port, n, steps, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, out = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got, out = _first_result(q, procs, 120)
     assert any(o[3] for o in ref_out)                                          # wall hits happened
     assert out == ref_out                                                       # per-step momentum / energy sums, bitwise
     for k in KEYS:
