@@ -490,6 +490,39 @@ def test_dense_cluster_chains_match_oracle(Engine, O):
         eng.close()
 
 
+@pytest.mark.parametrize("kind,n,sigma_mult,steps", [("cube", 30_000, 16.0, 25), ("pore", 60_000, 30.0, 25)])
+def test_high_collision_rate_stresses_the_wide_cluster_kernel(Engine, O, kind, n, sigma_mult, steps):
+    """A cross-section 16-30 times the reference's: several per cent of the particles collide in every step, so that
+    three- to ten-particle clusters, pulled-in particles, re-emulations and cluster-cluster conflicts (the concurrent
+    publish-then-probe protocol of k_clusters_wide) all happen in every sweep.  State and counters equal the oracle's bit
+    for bit at every step."""
+    sigma = 3.6e-19 * sigma_mult
+    if kind == "cube":
+        p, c = PR.cube_params_for_n(n, sigma=sigma)
+        init = IC.cube_ic(p, c, seed=41)
+    else:
+        p, c = PR.pore_params(n=n, sigma=sigma)
+        init = IC.pore_ic(p, c, seed=41)
+    p.detect_mode = 1
+    p.reserved1 = 1
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 22)
+    eng.upload(*init)
+    orc.upload(*init)
+    npp = rounds = 0
+    for s in range(steps):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0
+        for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"):
+            assert st[k] == so[k], (kind, s, k, st, so)
+        npp += st["n_pp"]
+        rounds += st["n_rounds"]
+        assert_state_equal(eng.download(), orc.state(), ("stress", kind, s))
+    assert npp > 0.01 * n * steps / 2, npp          # really a high collision rate
+    eng.close()
+
+
 def test_candidate_overflow_is_reported_not_silent(Engine):
     from argon_monte_carlo_amd._lib import ArgonMCError
     n = 3000
