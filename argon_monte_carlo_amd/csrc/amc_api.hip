@@ -91,15 +91,20 @@ static int setup_grid(amc_ctx *c)
         const double pi = 3.14159265358979323846;
         volume = 2 * pi * P.R_oa * P.R_oa * P.h_oa + pi * P.R_g * P.R_g * (P.H - 2 * P.h_oa);
     }
+    // list records hold positions relative to the grid origin in single precision: every test against them, and every box
+    // that selects the cells to probe, is widened by 16 roundings of the largest coordinate (guard cells included)
+    const double extent = 1.05 * std::max(xhi - xlo, zhi - zlo) + 8 * cr;
+    const double delta = std::max(1.0e-6, 16.0 * extent * 5.9604644775390625e-08 / cr);
+    const double crp = cr * (1.0 + delta);
     double h = P.fine_cell;
     if (!(h > 0)) {
         const double spacing = cbrt(volume / (double)std::max<int64_t>(1, c->n));
         // ~0.25 particles per cell: short lists (each further list element is a dependent random access) against more
         // cells per probe box; measured optimum on MI355X between 0.5 and 0.7 of the mean spacing
-        h = std::max(0.63 * spacing, 2.01 * cr);
+        h = std::max(0.63 * spacing, 2.01 * crp);
     }
     // probes look at the cells overlapped by a +-collision_range box: at most 2 per axis needs h >= 2*collision_range
-    if (h < 2.00001 * cr) return amc_fail(c, AMC_ERR_INVALID, "fine_cell %g must be at least 2x collision_range %g", h, cr);
+    if (h < 2.00001 * crp) return amc_fail(c, AMC_ERR_INVALID, "fine_cell %g must be at least 2x the probe radius %g (collision_range %g widened for the single-precision list records)", h, crp, cr);
     // keep the table bounded
     for (;;) {
         const double nxy = ceil((xhi - xlo) / h) + 2, nz = ceil((zhi - zlo) / h) + 2;
@@ -108,6 +113,8 @@ static int setup_grid(amc_ctx *c)
     }
     G.h = h;
     G.inv_h = 1.0 / h;
+    G.cr_probe = crp;
+    G.cr2_probe = crp * crp;
     G.uniform = (P.geometry == AMC_GEOM_CUBE) ? 1 : 0;
     G.x0 = xlo - h; G.y0 = xlo - h; G.z0 = zlo - h;           // one guard cell on every side
     G.gx = G.gy = (int)ceil((xhi - xlo) / h) + 2;

@@ -120,11 +120,13 @@ AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
     int h2 = skip_own(__hip_atomic_load(&W.ov_head[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     // pre-sweep positions of the particles binned into the cell
     while (q >= 0) {
-        const double4 r = A.B.rec[q];
+        const amc_rec r = A.B.rec[q];
         const int idx = q;
         q = amc_rec_next(r);
-        const double ax = r.x - x, ay = r.y - y, az = r.z - z;
-        if (!(ax * ax + ay * ay + az * az < cr2i)) continue;
+        double rx, ry, rz;
+        amc_rec_pos(A.G, r, rx, ry, rz);
+        const double ax = rx - x, ay = ry - y, az = rz - z;
+        if (!(ax * ax + ay * ay + az * az < A.G.cr2_probe)) continue;      // (single-precision record: widened test)
         bool mine = false;
         for (int m = 0; m < nm; m++) mine |= L.mem[own][m] == idx;
         if (mine) continue;
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
                     const cw_item it = L.item[t];
                     if (it.pad) continue;
                     for (int c = sub; c < 8; c += lpi) {
-                        const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.P.collision_range * 1.000001, c);
+                        const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.G.cr_probe, c);
                         if (cell >= 0) cw_probe_cell(A, wc, L, it, cell, cr2i, h_off);
                     }
                 }

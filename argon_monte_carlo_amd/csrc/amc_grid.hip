@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) {
-        const double4 me = B.rec[p];
+        const amc_rec me_r = B.rec[p];
+        double3 me;
+        amc_rec_pos(G, me_r, me.x, me.y, me.z);
         auto found_pair = [&](int q) { amc_push_candidate((int)p, q, max_cand, cnt, D); };
         // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
         // every same-cell pair is thereby met exactly once, by the later-inserted particle, and the head is not needed);
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
         // collision_range lie in each other's box, so a cross-cell pair is met exactly once, from the larger cell.  The kernel is bound by the LATENCY of dependent loads (head -> record -> next record),
         // so all cursors advance together: every round issues the loads of all live cursors before using any of them.
         int q[9];
-        q[0] = amc_rec_next(me);
+        q[0] = amc_rec_next(me_r);
         {
             int ocx, ocy, ocz;
             amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
@@ -128,14 +130,16 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
 #pragma unroll
             for (int e = 0; e < 9; e++) live |= q[e] >= 0;
             if (!live) break;
-            double4 o[9];
+            amc_rec o[9];
 #pragma unroll
             for (int e = 0; e < 9; e++)
                 if (q[e] >= 0) o[e] = B.rec[q[e]];
 #pragma unroll
             for (int e = 0; e < 9; e++)
                 if (q[e] >= 0) {
-                    const double ex = o[e].x - me.x, ey = o[e].y - me.y, ez = o[e].z - me.z;
+                    double ox, oy, oz;
+                    amc_rec_pos(G, o[e], ox, oy, oz);
+                    const double ex = ox - me.x, ey = oy - me.y, ez = oz - me.z;
                     if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q[e]);
                     q[e] = amc_rec_next(o[e]);
                 }
@@ -196,7 +200,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
 {
     const long long n = c->n;
     if (n <= 0) return hipSuccess;
-    const double cr2i = c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE;
+    const double cr2i = c->allpairs || c->detect_ap ? c->P.collision_range * c->P.collision_range * AMC_CR2_INFLATE : c->G.cr2_probe;
     amc_adj D;
     c->sweep_epoch = (c->sweep_epoch + 1u) & 0x3fffffffu;
     if (c->sweep_epoch == 0u) c->sweep_epoch = 1u;      // (0 is the value of the zero-initialised table)
@@ -215,7 +219,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
                                c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
     } else {
         hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
-                           c->P.collision_range * 1.000001, c->W.max_cand, c->d_cnt, D);
+                           c->G.cr_probe, c->W.max_cand, c->d_cnt, D);
     }
     amc_prof_end(c);
     return hipGetLastError();

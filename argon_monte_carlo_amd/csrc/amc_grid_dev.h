@@ -90,22 +90,31 @@ AMC_DEV int amc_grid_box_cell(const amc_grid &G, double x, double y, double z, d
 }
 
 // ---- per-cell lists -----------------------------------------------------------------------------------------------------
-AMC_DEV int amc_rec_next(const double4 &r) { return (int)__double_as_longlong(r.w); }
-AMC_DEV double amc_rec_pack(int next) { return __longlong_as_double((long long)next); }
+AMC_DEV int amc_rec_next(const amc_rec &r) { return r.next; }
+// position of a list record (absolute, double): what the particle was filed under, within the rounding of a float
+AMC_DEV void amc_rec_pos(const amc_grid &G, const amc_rec &r, double &x, double &y, double &z)
+{
+    x = G.x0 + (double)r.x; y = G.y0 + (double)r.y; z = G.z0 + (double)r.z;
+}
 // first particle of cell c in the current epoch, or -1
 AMC_DEV int amc_list_head(const amc_lists &B, int c)
 {
     const unsigned long long h = B.head[c];
     return ((unsigned int)(h >> 32) == B.epoch) ? (int)(unsigned int)(h & 0xffffffffULL) : -1;
 }
-// push particle p (position x,y,z) on the list of its cell; writes its record
+// push particle p (position x,y,z) on the list of its cell; writes its record.  The cell is the one of the ROUNDED position
+// (so that whoever reads the record back derives the same cell); probes cover the rounding through G.cr_probe.
 AMC_DEV void amc_list_insert(const amc_grid &G, const amc_lists &B, int p, double x, double y, double z, bool *outside)
 {
+    amc_rec r;
+    r.x = (float)(x - G.x0); r.y = (float)(y - G.y0); r.z = (float)(z - G.z0);
+    double rx, ry, rz;
+    amc_rec_pos(G, r, rx, ry, rz);
     int cx, cy, cz;
-    amc_grid_coords(G, x, y, z, cx, cy, cz);
+    amc_grid_coords(G, rx, ry, rz, cx, cy, cz);
     const int c = amc_grid_cell(G, cx, cy, cz, outside);
     const unsigned long long mine = ((unsigned long long)B.epoch << 32) | (unsigned int)p;
     const unsigned long long old = atomicExch(&B.head[c], mine);
-    const int next = ((unsigned int)(old >> 32) == B.epoch) ? (int)(unsigned int)(old & 0xffffffffULL) : -1;
-    B.rec[p] = make_double4(x, y, z, amc_rec_pack(next));
+    r.next = ((unsigned int)(old >> 32) == B.epoch) ? (int)(unsigned int)(old & 0xffffffffULL) : -1;
+    B.rec[p] = r;
 }

@@ -26,6 +26,9 @@ struct amc_grid {
     int uniform;              // 1: every layer stores the full gx*gy window (cube) -> no table lookups
     int gx, gy, gz;           // global extent in cells
     int ncells;               // stored cells = sum over layers of lay_n^2  (0 = no grid: all-pairs mode)
+    double cr_probe;          // collision_range * (1 + delta): radius of every box that is probed for list entries, and
+    double cr2_probe;         // its square: the distance test against a LIST RECORD's (single-precision) position.  delta
+                              // covers the rounding of the records (16 x extent x 2^-24 / collision_range, at least 1e-6)
     const int *lay_lo;        // [gz] first stored cell coordinate of the window (same for x and y)
     const int *lay_n;         // [gz] window edge in cells
     const int *lay_off;       // [gz] linear offset of the layer's first cell
@@ -34,10 +37,17 @@ struct amc_grid {
 // Per-cell particle lists of the detection grid, rebuilt every step with ONE 64-bit atomic exchange per particle:
 //   head[c] = (epoch << 32) | particle   — a head whose epoch is not the current one means "empty", so nothing is ever
 //                                          re-zeroed and no scan / scatter pass is needed;
-//   rec[p]  = (x, y, z, next-particle-as-bits) — 32 bytes, written coalesced (indexed by the particle itself).
+//   rec[p]  = (x, y, z relative to the grid origin in SINGLE precision, next particle) — 16 bytes, written coalesced
+//             (indexed by the particle itself).  The records only generate candidates and validation hits — supersets,
+//             re-tested exactly on the double-precision state — so half the bytes do; the particle is filed under the
+//             cell of its ROUNDED position, which the detect kernel recomputes from the same record.
+struct amc_rec {
+    float x, y, z;
+    int next;
+};
 struct amc_lists {
     unsigned long long *head; // [ncells]
-    double4 *rec;             // [n]
+    amc_rec *rec;             // [n]
     unsigned int epoch;       // current binning epoch (>= 1)
 };
 

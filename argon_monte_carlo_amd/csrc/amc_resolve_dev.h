@@ -775,7 +775,8 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     // only the cells overlapped by the collision_range box around the new position can hold a partner (2 to 3 on
     // average): fetch their list heads and overlay heads first, then the entries
     int c_lo[4], c_hi[4], lh[8], ovh[8];
-    const int ncell = amc_grid_box_ranges(G, x, y, z, A.P.collision_range * 1.000001, c_lo, c_hi);
+    const int ncell = amc_grid_box_ranges(G, x, y, z, G.cr_probe, c_lo, c_hi);
+    const double cr2g = G.cr2_probe;             // (list records are single precision: their test is widened, amc_internal.h)
     // list heads and overlay heads of every overlapped cell first (one memory round trip), then the entries
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -788,7 +789,8 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
     const int nx_me = W.ov_next[h], nx_pa = W.ov_next[h ^ 1];       // to step over my own / my partner's entry without a round trip
     // The probe is a chain of dependent memory round trips, so the FIRST element of every list (grid and overlay) is
     // fetched before any is examined; longer lists (rare at ~0.25 particles per cell) continue one element at a time.
-    double4 r0[RS_PF], o0[RS_PF];
+    amc_rec r0[RS_PF];
+    double4 o0[RS_PF];
     int on0[RS_PF];
 #pragma unroll
     for (int k = 0; k < RS_PF; k++) {
@@ -801,10 +803,12 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
             o0[k] = W.hist[h2]; on0[k] = W.ov_next[h2];
         }
     }
-    auto grid_entry = [&](int idx, const double4 &r) {
+    auto grid_entry = [&](int idx, const amc_rec &r) {
         if (idx == pme) return;
-        const double ax = r.x - x, ay = r.y - y, az = r.z - z;
-        if (ax * ax + ay * ay + az * az < cr2i) {
+        double rx, ry, rz;
+        amc_rec_pos(G, r, rx, ry, rz);
+        const double ax = rx - x, ay = ry - y, az = rz - z;
+        if (ax * ax + ay * ay + az * az < cr2g) {
             const int so = W.slot_of[idx];
             if (so >= 0 && so < ns && label[so] == lme) return;
             if (so < 0) rs_claim_slot(W, cnt, cap, idx);
@@ -824,14 +828,14 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         if (lh[k] >= 0) {
             grid_entry(lh[k], r0[k]);
             for (int q = amc_rec_next(r0[k]); q >= 0;) {
-                const double4 r = A.B.rec[q];
+                const amc_rec r = A.B.rec[q];
                 grid_entry(q, r);
                 q = amc_rec_next(r);
             }
         }
     for (int k = RS_PF; k < 2 * ncell; k++)
         for (int q = lh[k]; q >= 0;) {
-            const double4 r = A.B.rec[q];
+            const amc_rec r = A.B.rec[q];
             grid_entry(q, r);
             q = amc_rec_next(r);
         }
