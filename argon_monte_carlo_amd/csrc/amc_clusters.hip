@@ -35,7 +35,10 @@
 #define CW_MAXM 16          // particles of a component handled here
 #define CW_MAXC 24          // its candidates
 #define CW_ITEMS 192        // new positions one wave can publish + probe per pass (two per hit)
-#define CW_BLOCKS 512
+#define CW_BLOCKS 512       // waves of the launch
+#define CW_WPB 1            // waves per workgroup; each wave works on its own (its own part of the LDS, wave-level synchronisation
+                            // only).  Measured with 4 (128 workgroups of four waves, sharing instruction cache and LDS of a CU):
+                            // cube N = 1e5 51.0 instead of 48.0 us per step, pore N = 1e6 139.7 instead of 136 — one wave per CU it is
 
 AMC_DEV int cw_adj_head(const amc_resolve_ws &W, unsigned int epoch, int p)
 {
@@ -72,10 +75,10 @@ AMC_DEV double4 cw_load_hist(const amc_resolve_ws &W, int h)
 struct cw_lds {
     int mem[64][CW_MAXM];       // per owner lane: the particles of its cluster (ascending when emulated)
     int msl[64][CW_MAXM];       // and their slots
-    int cnd[64][CW_MAXC];       // its candidates: candidate c brings slots 2c, 2c + 1 and the history pair (2c, 2c + 1)
+    int cnd[64][CW_MAXC];       // its candidates: candidate c brings slots 2c, 2c + 1 and the history pairs 4c, 4c + 2
     int pull[64][CW_PULLS], psl[64][CW_PULLS];     // particles (and their new slots) the last validation pulled in
     int nm[64], nc[64], lab[64], npull[64];         // members, candidates, cluster label (= first slot), pulls
-    int hb[64][CW_ITERS], he[64][CW_ITERS], it0[64][CW_ITERS];   // per emulation: reserved range (re-emulations), first work item
+    int it0[64];                // first work item of the owner's current emulation (its items are contiguous, in hit order)
     int used[64];               // history pairs the running emulation has taken
     int redo[64];               // the cluster must be emulated (again) by the wave
     int gen[64];                // emulations done
@@ -88,37 +91,20 @@ struct cw_lds {
     uint8_t pool_flag[CW_MAXM], pool_moved[CW_MAXM];
 };
 
-// One cell of the probe of one published position: everything outside its cluster within the (inflated) collision range
-// either joins the cluster (a particle that is in no candidate and that nobody else has taken: the owner emulates again
-// with it) or becomes a merge edge for the ordered workgroup.  The (up to eight) cells of a position's box go to different
-// lanes when the wave has lanes to spare — the probe is a chain of dependent round trips plus a few hundred instructions
-// per cell, and a lone wave issues one instruction every ~2 ns.
-AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, int cell, double cr2i, int h_off)
+// The validation of a new position has two halves.  GRID half: the pre-sweep positions of everything outside the cluster
+// (the detection grid's lists) — needs nothing from other workgroups, so it runs right after the emulation, before
+// anything is published: a particle that is in no candidate and that nobody else has taken JOINS the cluster (the owner
+// emulates again with it, and what it had emulated so far is simply dropped: it was never visible to anybody); anything
+// else becomes a merge edge for the ordered workgroup.  OVERLAY half: the other clusters' new positions, after the
+// cluster's final positions have been published (publish-then-probe, see the header).  One call handles ONE cell of the
+// position's box; the (up to eight) cells go to different lanes while the wave has lanes to spare — the probe is a chain
+// of dependent round trips plus a few hundred instructions per cell, and a lone wave issues one instruction every ~2 ns.
+AMC_DEV void cw_probe_grid(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, int cell, int s_off)
 {
     const amc_resolve_ws &W = A.W;
     const int own = me.own, nm = L.nm[own], lab = L.lab[own];
     const double x = me.x, y = me.y, z = me.z;
-    // entries of my own cluster (of this and of earlier emulations) are stepped over through the `next` values their
-    // pushes returned (LDS), without a load
-    auto skip_own = [&](int h2) {
-        while (h2 >= 0) {
-            int t = -1;
-            if (h2 < h_off) {                               // a candidate's own pair: mine if the candidate is
-                const int c = h2 >> 1, ncs = L.nc[own];
-                for (int q = 0; q < ncs; q++)
-                    if (L.cnd[own][q] == c) { t = L.it0[own][0] + 2 * q + (h2 & 1); break; }
-            } else {
-                for (int r = 1; r < CW_ITERS; r++)
-                    if (h2 >= L.hb[own][r] && h2 < L.he[own][r]) { t = L.it0[own][r] + (h2 - L.hb[own][r]); break; }
-            }
-            if (t < 0) break;
-            h2 = L.next[t];
-        }
-        return h2;
-    };
     int q = amc_list_head(A.B, cell);
-    int h2 = skip_own(__hip_atomic_load(&W.ov_head[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    // pre-sweep positions of the particles binned into the cell
     while (q >= 0) {
         const amc_rec r = A.B.rec[q];
         const int idx = q;
@@ -136,7 +122,7 @@ AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
             const int old = atomicCAS(&W.slot_of[idx], -1, tag);
             if (old == tag) continue;                           // another position of my cluster found it too
             if (old == -1) {
-                const int s = h_off + atomicAdd(&wc->nslots, 1);
+                const int s = s_off + atomicAdd(&wc->nslots, 1);
                 const int k = atomicAdd(&L.npull[own], 1);
                 if (s < W.max_slots && k < CW_PULLS) {
                     L.pull[own][k] = idx; L.psl[own][k] = s;   // (slot_of keeps the tag until the owner initialises the slot)
@@ -150,7 +136,27 @@ AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
         }
         rs_add_edge(W, wc, me.p, idx);
     }
-    // new positions of other clusters' members
+}
+
+AMC_DEV void cw_probe_overlay(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_item &me, int cell, double cr2i, int h_off)
+{
+    const amc_resolve_ws &W = A.W;
+    const int own = me.own, nm = L.nm[own];
+    const double x = me.x, y = me.y, z = me.z;
+    // the published entries of my own cluster — the pairs its candidates brought along, in the order its final emulation
+    // took them — are stepped over through the `next` values their pushes returned (LDS), without a load
+    auto skip_own = [&](int h2) {
+        while (h2 >= 0 && h2 < h_off) {
+            const int c = h2 >> 2, second = (h2 >> 1) & 1, ncs = L.nc[own];
+            int t = -1;
+            for (int q = 0; q < ncs; q++)
+                if (L.cnd[own][q] == c) { t = L.it0[own] + 2 * (q + second * ncs) + (h2 & 1); break; }
+            if (t < 0) break;
+            h2 = L.next[t];
+        }
+        return h2;
+    };
+    int h2 = skip_own(__hip_atomic_load(&W.ov_head[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     while (h2 >= 0) {
         const double4 o = cw_load_hist(W, h2);
         const int nx = __hip_atomic_load(&W.ov_next[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -161,19 +167,19 @@ AMC_DEV void cw_probe_cell(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
         bool mine = false;
         for (int m = 0; m < nm; m++) mine |= L.msl[own][m] == s2;
         if (mine) continue;
-        // position of an emulation that was redone since?  (its owner raised the slot's round before it published anew)
+        // (only final emulations are ever published, but the ordered workgroup's rounds are told apart the same way)
         if (rs_hist_gen(o) != __hip_atomic_load(((int *)&W.sl_meta[s2]) + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
         rs_add_edge(W, wc, me.p, -(s2 + 2));                    // (the other end as a slot)
     }
 }
 
 // Before an owner's cluster is emulated (again): the particles its last validation pulled in become members (kept in
-// ascending particle index, slots alongside), a re-emulation gets a contiguous range of history pairs from the counter.
-// Run by ONE lane per owner.  Returns the number of members.
+// ascending particle index, slots alongside).  The emulation starts over with the history pairs its candidates brought
+// along: what the dropped emulation wrote there was never published.  Run by ONE lane per owner.  Returns the number of members.
 AMC_DEV int cw_prepare(const amc_resolve_ws &W, rs_shared *wc, cw_lds &L, int own, int h_off)
 {
     int m = L.nm[own];
-    const int g = L.gen[own], lab = L.lab[own];
+    const int lab = L.lab[own];
     const int np = L.npull[own] < CW_PULLS ? L.npull[own] : CW_PULLS;
     L.unv[own] = 0;
     for (int e = 0; e < np; e++) {
@@ -189,26 +195,18 @@ AMC_DEV int cw_prepare(const amc_resolve_ws &W, rs_shared *wc, cw_lds &L, int ow
         m++;
     }
     L.nm[own] = m; L.npull[own] = 0;
-    if (g > 0) {
-        const int want = 2 * (L.nc[own] + m);
-        const int hb = h_off + atomicAdd(&wc->nhist, want);
-        if (hb + want > W.max_hist) { wc->ovf = 1; L.hb[own][g] = 0; L.he[own][g] = 0; }
-        else {
-            L.hb[own][g] = hb; L.he[own][g] = hb + want;
-            for (int e = hb; e < hb + want; e++) W.ev_gen[e] = 0;
-        }
-    }
     L.used[own] = 0;
+    L.it0[own] = -1;
     return m;
 }
 
 AMC_DEV void cw_wide_hooks(rs_wide &wd, cw_lds &L, int own, int h_off)
 {
     const int g = L.gen[own];
-    wd.cnd = g == 0 ? L.cnd[own] : nullptr; wd.ncnd = L.nc[own]; wd.range_hb = L.hb[own][g]; wd.range_he = L.he[own][g];
+    wd.cnd = L.cnd[own]; wd.ncnd = L.nc[own];
     wd.used = &L.used[own]; wd.h_off = h_off;
     wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own][g]; wd.unval = &L.unv[own];
+    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own]; wd.unval = &L.unv[own];
 }
 
 // slots of the cluster's candidates (first emulation only)
@@ -222,26 +220,29 @@ AMC_DEV void cw_candidate_slots(const amc_resolve_ws &W, cw_lds &L, int own, int
 }
 
 template <int GEOM>
-__global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
+__global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kernarg)
 {
     RS_STAGE_ARGS(A);
     const amc_resolve_ws &W = A.W;
     rs_shared *wc = (rs_shared *)W.wctl;
-    __shared__ cw_lds L;
-    const int lane = threadIdx.x;
-    const int nwaves = gridDim.x;
+    __shared__ cw_lds L_all[CW_WPB];
+    cw_lds &L = L_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const int nwaves = gridDim.x * CW_WPB;
+    const int wave_id = blockIdx.x * CW_WPB + (threadIdx.x >> 6);
     const long long t_enter__ = A.dbg ? wall_clock64() : 0;
     const int per = A.wide_per;         // candidates per wave and pass, fixed by the host: the first pass's candidate is
                                         // known before the sweep's candidate count has arrived
     // speculative: record and state of my first candidate (valid memory for any k below the capacity)
-    const int k_first = blockIdx.x * per + lane;
+    const int k_first = wave_id * per + lane;
     int4 c4_first = make_int4(0, 0, -1, -1);
     if (lane < per && k_first < W.max_cand) c4_first = W.cand4[k_first];
     int ncand = (int)A.O.cnt->cand_count;
     if (ncand > W.max_cand) ncand = W.max_cand;
-    if (blockIdx.x == 0 && lane == 0) { wc->active = 1; wc->ncand = ncand; }
+    if (wave_id == 0 && lane == 0) { wc->active = 1; wc->ncand = ncand; }
     if (ncand == 0) return;
-    const int h_off = 2 * ncand;        // first counter-allocated slot / history entry of this sweep
+    const int s_off = 2 * ncand;        // first counter-allocated slot of this sweep (candidate k owns slots 2k, 2k + 1)
+    const int h_off = 4 * ncand;        // first counter-allocated history entry (candidate k owns the pairs 4k and 4k + 2)
     const double cr2i = A.P.collision_range * A.P.collision_range * AMC_CR2_INFLATE;
     rs_work K;
     K.x = L.pool_d[0]; K.y = L.pool_d[1]; K.z = L.pool_d[2]; K.vx = L.pool_d[3]; K.vy = L.pool_d[4]; K.vz = L.pool_d[5];
@@ -260,8 +261,9 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
             t_last = now__;                                                                \
         }                                                                                  \
     } while (0)
-    const bool timed__ = A.dbg && lane == 0 && blockIdx.x * per < ncand;     // waves with work in their first pass
-    for (int k0 = blockIdx.x * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
+    const bool timed__ = A.dbg && lane == 0 && wave_id * per < ncand;     // waves with work in their first pass
+    int cat__ = 0;
+    for (int k0 = wave_id * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
         const bool valid = lane < per && k < ncand;
         if (lane == 0) L.nitems = 0;
@@ -320,20 +322,21 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
         const bool take = iso || owner;
         L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = 2 * k; L.npull[lane] = 0;
         for (int m = 0; m < nm; m++) L.msl[lane][m] = 2 * cnd[m >> 1] + (m & 1);
-        for (int r = 0; r < CW_ITERS; r++) { L.hb[lane][r] = 0; L.he[lane][r] = 0; L.it0[lane][r] = -1; }
+        L.it0[lane] = -1;
         L.redo[lane] = take ? 1 : 0;
         L.gen[lane] = 0;
+        if (timed__) cat__ = !take ? 3 : (nm == 2 ? 0 : (nm == 3 ? 1 : 2));
         {
             // statistics: one counter per bank of waves (2000 waves adding to ONE word are a 24 us chain of same-address atomics)
             const int ncl = __popcll(__ballot(take));
-            if (lane == 0 && ncl) atomicAdd(&W.wctl[32 + (blockIdx.x & 15)], ncl);
+            if (lane == 0 && ncl) atomicAdd(&W.wctl[32 + (wave_id & 15)], ncl);
         }
-        __syncthreads();
+        rs_wave_sync();
         CW_STAMP(2);
         int first_item = 0;
         for (int iter = 0; iter < CW_ITERS; iter++) {
             // ---- 3a. clusters of two or three particles: one lane each, everything in registers ----------------------------------
-            __syncthreads();
+            rs_wave_sync();
             int my_m = 0;
             if (L.redo[lane]) my_m = cw_prepare(W, wc, L, lane, h_off);
             if (L.redo[lane] && my_m <= 3) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
             // the ones just pulled in too, get their slots there, and the self edge hands it to the ordered workgroup)
             CW_STAMP(3);
             // ---- 3b. larger clusters, one after the other by the whole wave (working set in LDS) ---------------------------------
-            __syncthreads();
+            rs_wave_sync();
             unsigned long long todo = __ballot(L.redo[lane] != 0);
             while (todo) {
                 const int src = __ffsll((long long)todo) - 1;
@@ -389,30 +392,66 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
                 }
                 if (g == 0)
                     for (int e = lane; e < ncs; e += 64) cw_candidate_slots(W, L, src, e);
-                __syncthreads();
+                rs_wave_sync();
                 rs_wide wd;
                 cw_wide_hooks(wd, L, src, h_off);
                 if (m <= RS_COOP_MAX) rs_emulate_coop(A, wc, K, 0, m, &wd);
                 else if (lane == 0) rs_emulate_generic(A, wc, K, 0, m, &wd);
-                __syncthreads();
+                rs_wave_sync();
                 if (lane < m && K.moved[lane]) rs_store_slot(W, K.slot[lane], rs_load_work(K, lane));
                 if (lane == 0) {
                     if (L.unv[src]) rs_add_edge(W, wc, K.pidx[0], K.pidx[0]);  // (self edge: the ordered workgroup redoes it)
                     L.gen[src] = g + 1;
                     L.redo[src] = 0;
                 }
-                __syncthreads();
+                rs_wave_sync();
             }
             CW_STAMP(4);
-            // ---- 4. publish every new position of this turn, then probe them ----------------------------------------------------
-            __syncthreads();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the history records (write-through stores) have left
+            // ---- 4a. GRID half of the validation, straight after the emulation (nothing has been published yet) ------------------
+            rs_wave_sync();
             const int nit = L.nitems < CW_ITEMS ? L.nitems : CW_ITEMS;
-            for (int t0 = first_item; t0 < nit; t0 += 64) {
-                const int t = t0 + lane;
-                if (t < nit) L.next[t] = -1;
-                if (t < nit && !L.item[t].pad) {
+            {
+                // the cells of a position's box go to different lanes while the wave has lanes to spare
+                const int nnew = nit - first_item;
+                const int lpi = nnew <= 8 ? 8 : (nnew <= 16 ? 4 : (nnew <= 32 ? 2 : 1));       // lanes per item
+                const int sub = lane % lpi;
+                for (int t = first_item + lane / lpi; t < nit; t += 64 / lpi) {
                     const cw_item it = L.item[t];
+                    if (it.pad & 1) continue;
+                    for (int c = sub; c < 8; c += lpi) {
+                        const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.G.cr_probe, c);
+                        if (cell >= 0) cw_probe_grid(A, wc, L, it, cell, s_off);
+                    }
+                }
+            }
+            first_item = nit;
+            CW_STAMP(6);
+            // a cluster that pulled particles in is emulated again from the untouched pre-sweep state (what it emulated so far
+            // was never published: it is simply dropped), unless it has had its turns: then the particles still get their
+            // slots and the ordered workgroup takes over
+            if (!__ballot(L.redo[lane] != 0)) break;
+            if (A.dbg && lane == 0) A.dbg[24] = 1;          // (diagnostic: this launch has a wave that emulates again)
+            if (timed__ && L.redo[0]) cat__ |= 4;
+            if (iter + 1 == CW_ITERS || L.nitems >= CW_ITEMS - 8) {
+                if (L.redo[lane]) {
+                    const int np = L.npull[lane] < CW_PULLS ? L.npull[lane] : CW_PULLS;
+                    for (int e = 0; e < np; e++) cw_init_slot(W, L.psl[lane][e], L.pull[lane][e], L.lab[lane], 0);
+                    rs_add_edge(W, wc, L.mem[lane][0], L.mem[lane][0]);
+                    L.redo[lane] = 0;
+                }
+                break;
+            }
+        }
+        // ---- 4b. publish the positions of every cluster's FINAL emulation, then the OVERLAY half of their validation ------------
+        rs_wave_sync();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the history records (write-through stores) have left
+        const int nit = L.nitems < CW_ITEMS ? L.nitems : CW_ITEMS;
+        for (int t0 = 0; t0 < nit; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < nit) L.next[t] = -1;
+            if (t < nit) {
+                const cw_item it = L.item[t];
+                if (!(it.pad & 1) && (it.pad >> 1) == L.gen[it.own]) {  // (an item of a dropped emulation is skipped)
                     int cx, cy, cz;
                     amc_grid_coords(A.G, it.x, it.y, it.z, cx, cy, cz);
                     const int cell = amc_grid_cell(A.G, cx, cy, cz, nullptr);
@@ -427,39 +466,23 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
                     L.next[t] = expected;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every push of this wave has returned
-            __syncthreads();
-            CW_STAMP(5);
-            {
-                // the cells of a position's box go to different lanes while the wave has lanes to spare
-                const int nnew = nit - first_item;
-                const int lpi = nnew <= 8 ? 8 : (nnew <= 16 ? 4 : (nnew <= 32 ? 2 : 1));       // lanes per item
-                const int sub = lane % lpi;
-                for (int t = first_item + lane / lpi; t < nit; t += 64 / lpi) {
-                    const cw_item it = L.item[t];
-                    if (it.pad) continue;
-                    for (int c = sub; c < 8; c += lpi) {
-                        const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.G.cr_probe, c);
-                        if (cell >= 0) cw_probe_cell(A, wc, L, it, cell, cr2i, h_off);
-                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every push of this wave has returned
+        rs_wave_sync();
+        CW_STAMP(5);
+        {
+            const int lpi = nit <= 8 ? 8 : (nit <= 16 ? 4 : (nit <= 32 ? 2 : 1));
+            const int sub = lane % lpi;
+            for (int t = lane / lpi; t < nit; t += 64 / lpi) {
+                const cw_item it = L.item[t];
+                if ((it.pad & 1) || (it.pad >> 1) != L.gen[it.own]) continue;
+                for (int c = sub; c < 8; c += lpi) {
+                    const int cell = amc_grid_box_cell(A.G, it.x, it.y, it.z, A.G.cr_probe, c);
+                    if (cell >= 0) cw_probe_overlay(A, wc, L, it, cell, cr2i, h_off);
                 }
-            }
-            first_item = nit;
-            CW_STAMP(6);
-            // a cluster that pulled particles in is emulated again from the untouched pre-sweep state, unless it has had
-            // its turns: then the particles still get their slots and the ordered workgroup takes over
-            if (!__syncthreads_or(L.redo[lane])) break;
-            if (A.dbg && lane == 0) A.dbg[24] = 1;          // (diagnostic: this launch has a wave that emulates again)
-            if (iter + 1 == CW_ITERS || L.nitems >= CW_ITEMS - 8) {
-                if (L.redo[lane]) {
-                    const int np = L.npull[lane] < CW_PULLS ? L.npull[lane] : CW_PULLS;
-                    for (int e = 0; e < np; e++) cw_init_slot(W, L.psl[lane][e], L.pull[lane][e], L.lab[lane], 0);
-                    rs_add_edge(W, wc, L.mem[lane][0], L.mem[lane][0]);
-                }
-                break;
             }
         }
-        __syncthreads();
+        rs_wave_sync();
     }
     if (A.dbg && lane == 0) {       // span of the launch as the device sees it: first wave in, last wave out
         atomicMin((unsigned long long *)&A.dbg[28], (unsigned long long)t_enter__);
@@ -467,6 +490,9 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
     }
     if (timed__) {
         atomicMax((unsigned long long *)&A.dbg[30], (unsigned long long)(wall_clock64() - t_enter__));
+        atomicAdd((unsigned long long *)&A.dbg[32 + 2 * cat__], (unsigned long long)(wall_clock64() - t_enter__));
+        atomicAdd((unsigned long long *)&A.dbg[33 + 2 * cat__], 1ULL);
+        if (cat__ == 0) { int b = (int)((wall_clock64() - t_enter__) / 250); if (b > 15) b = 15; atomicAdd((unsigned long long *)&A.dbg[48 + b], 1ULL); }
         atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
         for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[16 + e], (unsigned long long)t_acc[e]);
     }
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(64) void k_clusters_wide(rs_args A_in_kernarg)
 int amc_clusters_wide_blocks(amc_ctx *c)
 {
     static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
-    if (nb_env > 0) return nb_env;
+    if (nb_env > 0) return (nb_env + CW_WPB - 1) / CW_WPB * CW_WPB;
     return CW_BLOCKS;
 }
 
@@ -483,8 +509,8 @@ hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
 {
     const int nb = amc_clusters_wide_blocks(c);
     switch (c->P.geometry) {
-    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3(nb), dim3(64), 0, c->stream, A); break;
-    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3(nb), dim3(64), 0, c->stream, A); break;
+    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3((nb + CW_WPB - 1) / CW_WPB), dim3(64 * CW_WPB), 0, c->stream, A); break;
+    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3((nb + CW_WPB - 1) / CW_WPB), dim3(64 * CW_WPB), 0, c->stream, A); break;
     }
     return hipGetLastError();
 }

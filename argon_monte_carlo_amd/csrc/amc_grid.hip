@@ -46,7 +46,7 @@ struct amc_adj {
     unsigned long long *head;   // [n]   nullptr: the graph is not needed (all-pairs mode)
     int4 *rec;                  // [max_cand] (i, j, next in i's list, next in j's list)
     int4 *sd;                   // [max_cand] (slot of i, slot of j, done, -): reset here
-    // candidate k brings its own two slots (2k, 2k + 1) and its own pair of history / event entries (2k, 2k + 1): whoever
+    // candidate k brings its own two slots (2k, 2k + 1) and two pairs of history / event entries (4k .. 4k + 3): whoever
     // emulates the candidate's cluster uses them without any allocation; here they are marked empty
     int4 *sl_meta;
     int *sl_hits, *ev_gen;
@@ -73,8 +73,7 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
             D.sl_meta[2 * k + 1] = make_int4(-1, 2 * (int)k + 1, 0, 0);
             atomicAnd(&D.sl_hits[2 * k], 0);    // (atomics, like the increments: no value needed back)
             atomicAnd(&D.sl_hits[2 * k + 1], 0);
-            D.ev_gen[2 * k] = 0;
-            D.ev_gen[2 * k + 1] = 0;
+            *(int4 *)&D.ev_gen[4 * k] = make_int4(0, 0, 0, 0);      // (its two pairs of history / event entries: 4k .. 4k + 3)
         }
         return (int)k;
     }

@@ -85,12 +85,12 @@ __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
         wide_ns = -1; wide_nh = 0; wide_dirty = 0; s_left = 0;
         sh.nslots = 0; sh.nhist = 0; sh.nev = 0; sh.nfp = 0; sh.ovf = 0; sh.nedges = 0; sh.nclusters = 0;
         if (MODE == 0 && A.wide_plan) {
-            // (candidate k owns slots 2k, 2k + 1 and the history pair (2k, 2k + 1); what the wide kernel took from its
+            // (candidate k owns slots 2k, 2k + 1 and the history pairs 4k, 4k + 2; what the wide kernel took from its
             // counters comes after those)
             rs_shared *wc = (rs_shared *)W.wctl;
             const int off = 2 * ncand;
             sh.nslots = off + wc->nslots < W.max_slots ? off + wc->nslots : W.max_slots;
-            sh.nhist = off + wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges;
+            sh.nhist = 2 * off + wc->nhist; sh.nfp = wc->nfp; sh.ovf = wc->ovf; sh.nedges = wc->nedges;
             sh.nclusters = 0;
             for (int b = 0; b < 16; b++) { sh.nclusters += W.wctl[32 + b]; W.wctl[32 + b] = 0; }      // (banked by the wide kernel's waves)
             wide_dirty = wc->dirty;

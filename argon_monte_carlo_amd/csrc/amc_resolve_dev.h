@@ -139,16 +139,15 @@ AMC_DEV int rs_count_add(int *counter, int n)
 // publish-and-probe phase that follows the emulation.  nullptr inside the ordered workgroup.
 struct cw_item {
     double x, y, z;
-    int h, own, p, pad;       // history entry, owner lane (its member list / slot range), particle
+    int h, own, p, pad;       // history entry, owner lane (its member list / slots), particle; pad = failed hit | emulation round << 1
 };
 struct rs_wide {
-    // where the hit's pair of history entries comes from: the cluster's candidates bring one pair each (2c, 2c + 1, first
-    // emulation), a re-emulation has a contiguous range; beyond that the counter (then the ordered workgroup redoes it)
-    const int *cnd;           // candidates of the cluster (nullptr: use the range)
+    // where the hit's pair of history entries comes from: the cluster's candidates bring two pairs each (4c, 4c + 2);
+    // beyond that the counter (then the ordered workgroup redoes the cluster)
+    const int *cnd;           // candidates of the cluster
     int ncnd;
-    int range_hb, range_he;
     int *used;                // pairs taken so far
-    int h_off;                // first counter-allocated entry of this sweep (2 * ncand)
+    int h_off;                // first counter-allocated entry of this sweep (4 * ncand)
     cw_item *items;           // work items of the wave (LDS)
     int *nitems;
     int cap;
@@ -182,9 +181,12 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     // the hit's pair of history entries (h: particle j, h + 1: particle i); its events use the same two indices
     int h = -1;
     if (wd) {
+        // every candidate of the cluster brings TWO pairs of entries (4c, 4c + 2): hit q takes the first pairs in the order
+        // of the candidate list, then the second ones (a cluster that pulled a particle in usually hits once more than it has
+        // candidates); beyond that the counter — unpublishable here, so the ordered workgroup redoes the cluster
         const int q = (*wd->used)++;
-        if (wd->cnd) { if (q < wd->ncnd) h = 2 * wd->cnd[q]; }
-        else if (wd->range_hb + 2 * q + 2 <= wd->range_he) h = wd->range_hb + 2 * q;
+        if (q < wd->ncnd) h = 4 * wd->cnd[q];
+        else if (q < 2 * wd->ncnd) h = 4 * wd->cnd[q - wd->ncnd] + 2;
         if (h < 0) { h = wd->h_off + rs_count_add(&sh->nhist, 2); *wd->unval = 1; }
     } else {
         h = rs_count_add(&sh->nhist, 2);
@@ -218,8 +220,8 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
             if (it + 2 <= wd->cap) {
                 if (*wd->it0 < 0) *wd->it0 = it;             // the owner's items are contiguous, in the order of its reserved entries
                 cw_item a, b;
-                a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd->own; a.p = pj; a.pad = fail;
-                b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd->own; b.p = pi; b.pad = fail;
+                a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd->own; a.p = pj; a.pad = fail | (wd->gen << 1);
+                b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd->own; b.p = pi; b.pad = fail | (wd->gen << 1);
                 wd->items[it] = a;
                 wd->items[it + 1] = b;
             } else {
