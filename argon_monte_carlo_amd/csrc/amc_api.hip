@@ -353,8 +353,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         c->h_pin_bytes = (size_t)4 << 20;
         if (hipHostMalloc((void **)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; c->h_pin_bytes = 0; }
         if (getenv("AMC_DEBUG_RESOLVE")) {
-            CK(dalloc(&c->d_dbg, 64));
-            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 64, c->stream));
+            CK(dalloc(&c->d_dbg, 80));
+            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 80, c->stream));
             { const long long big = 0x7fffffffffffffffLL; CK(hipMemcpyAsync(c->d_dbg + 28, &big, sizeof big, hipMemcpyHostToDevice, c->stream)); }
         }
         CK(hipStreamSynchronize(c->stream));
@@ -763,7 +763,7 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
     hipSetDevice(c->device);
     amc_prof_collect(c);
     if (c->d_dbg) {
-        long long h[64];
+        long long h[80];
         hipMemcpy(h, c->d_dbg, sizeof h, hipMemcpyDeviceToHost);
         const double n = h[11] > 0 ? (double)h[11] : 1.0;
         fprintf(stderr, "[amc k_resolve phases, us/launch] count-left %.1f claim %.1f | rounds: collect %.1f pairs %.1f clusters>=3: sort+load %.1f emulate %.1f | overlay %.1f validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
@@ -778,6 +778,7 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
             for (int k = 0; k < 16; k++) fprintf(stderr, " %lld", h[48 + k]);
             fprintf(stderr, "\n");
         }
+        if (h[71]) fprintf(stderr, "[pair waves that lived > 20 us (%lld), us] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f\n", h[71], h[64] / (double)h[71] / 100.0, h[65] / (double)h[71] / 100.0, h[66] / (double)h[71] / 100.0, h[67] / (double)h[71] / 100.0, h[68] / (double)h[71] / 100.0, h[69] / (double)h[71] / 100.0, h[70] / (double)h[71] / 100.0);
         fprintf(stderr, "[amc k_clusters_wide phases, us per working wave] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f | waves %lld | launch span (first wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us; launches with a re-emulation: %lld, their span %.2f us, the others' %.2f us\n",
                 h[16] / w / 100.0, h[17] / w / 100.0, h[18] / w / 100.0, h[19] / w / 100.0, h[20] / w / 100.0, h[21] / w / 100.0, h[22] / w / 100.0, h[31],
                 h[27] / n / 100.0, h[26] / n / 100.0, h[30] / 100.0, h[25], h[25] ? h[23] / (double)h[25] / 100.0 : 0.0,

@@ -495,6 +495,10 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         if (cat__ == 0) { int b = (int)((wall_clock64() - t_enter__) / 250); if (b > 15) b = 15; atomicAdd((unsigned long long *)&A.dbg[48 + b], 1ULL); }
         atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
         for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[16 + e], (unsigned long long)t_acc[e]);
+        if (cat__ == 0 && wall_clock64() - t_enter__ > 2000) {       // the slow pair waves (> 20 us): where did they spend it?
+            for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[64 + e], (unsigned long long)t_acc[e]);
+            atomicAdd((unsigned long long *)&A.dbg[71], 1ULL);
+        }
     }
 }
 
