@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 #include <new>
 #include <type_traits>
 
@@ -297,7 +298,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
                     off += sizeof(T) * std::max<size_t>(count, 1);
                 };
                 take(&W.ctl, 64); take(&W.wctl, 64);
-                take(&W.cand4, (size_t)W.max_cand); take(&W.cand_s, (size_t)W.max_cand);
+                take(&W.cand4, (size_t)W.max_cand); take(&W.cand_s, (size_t)W.max_cand); take(&W.cand_mark, (size_t)W.max_cand);
                 take(&W.sl_meta, ms); take(&W.sl_hits, ms); take(&W.sl_moved, ms);
                 take(&W.sl_state, (size_t)RS_SLOT_DOUBLES * ms);
                 take(&W.sl_label, ms); take(&W.sl_tmp, ms); take(&W.sl_dirty, ms); take(&W.order, ms);
@@ -353,8 +354,8 @@ int amc_create(amc_ctx **out, const amc_params *p)
         c->h_pin_bytes = (size_t)4 << 20;
         if (hipHostMalloc((void **)&c->h_pin, c->h_pin_bytes, hipHostMallocDefault) != hipSuccess) { c->h_pin = nullptr; c->h_pin_bytes = 0; }
         if (getenv("AMC_DEBUG_RESOLVE")) {
-            CK(dalloc(&c->d_dbg, 80));
-            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * 80, c->stream));
+            CK(dalloc(&c->d_dbg, 128 + 128 * 512));
+            CK(hipMemsetAsync(c->d_dbg, 0, sizeof(long long) * (128 + 128 * 512), c->stream));
             { const long long big = 0x7fffffffffffffffLL; CK(hipMemcpyAsync(c->d_dbg + 28, &big, sizeof big, hipMemcpyHostToDevice, c->stream)); }
         }
         CK(hipStreamSynchronize(c->stream));
@@ -763,26 +764,36 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
     hipSetDevice(c->device);
     amc_prof_collect(c);
     if (c->d_dbg) {
-        long long h[80];
+        long long h[128];
         hipMemcpy(h, c->d_dbg, sizeof h, hipMemcpyDeviceToHost);
         const double n = h[11] > 0 ? (double)h[11] : 1.0;
         fprintf(stderr, "[amc k_resolve phases, us/launch] count-left %.1f claim %.1f | rounds: collect %.1f pairs %.1f clusters>=3: sort+load %.1f emulate %.1f | overlay %.1f validate %.1f commit %.1f | rounds %.2f cand %.1f complex-members %.2f launches %lld\n",
                 h[0] / n / 100.0, h[1] / n / 100.0, h[6] / n / 100.0, h[7] / n / 100.0, h[2] / n / 100.0, h[3] / n / 100.0, h[14] / n / 100.0, h[4] / n / 100.0, h[5] / n / 100.0,
                 h[8] / n, h[9] / n, h[10] / n, h[11]);
-        const double w = h[31] > 0 ? (double)h[31] : 1.0;
         {
+            // the wide kernel's waves keep their figures in 64 words each (amc_clusters.hip)
+            std::vector<long long> wv((size_t)128 * 512);
+            hipMemcpy(wv.data(), c->d_dbg + 128, sizeof(long long) * wv.size(), hipMemcpyDeviceToHost);
+            long long s[128] = {0}, longest = 0;
+            for (int w = 0; w < 512; w++) {
+                for (int e = 3; e < 128; e++) if (e != 4) s[e] += wv[(size_t)128 * w + e];
+                longest = std::max(longest, wv[(size_t)128 * w + 4]);
+            }
+            const double nl = h[25] > 0 ? (double)h[25] : 1.0;
             static const char *cn[8] = {"pair", "3-cluster", "4+-cluster", "not owner", "pair+again", "3-cluster+again", "4+-cluster+again", "not owner+again"};
-            fprintf(stderr, "[amc k_clusters_wide wave lifetime by kind, us (count)]");
-            for (int k = 0; k < 8; k++) if (h[33 + 2 * k]) fprintf(stderr, " %s %.1f (%lld)", cn[k], h[32 + 2 * k] / (double)h[33 + 2 * k] / 100.0, h[33 + 2 * k]);
-            fprintf(stderr, "\n[pair-wave lifetimes, 2.5 us buckets]");
-            for (int k = 0; k < 16; k++) fprintf(stderr, " %lld", h[48 + k]);
+            static const char *pn[11] = {"graph", "walk", "reserve", "small: emulate + grid probe", "by the wave: emulate", "publish", "by the wave: grid probe", "first hop", "particles", "set-up", "overlay probe"};
+            fprintf(stderr, "[amc k_clusters_wide] working waves %lld in %lld launches; launch span (first working wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us\n",
+                    s[3], h[25], h[27] / nl / 100.0, h[26] / nl / 100.0, longest / 100.0);
+            fprintf(stderr, "[pair-wave lifetimes, 2.5 us buckets]");
+            for (int k = 0; k < 8; k++) fprintf(stderr, " %lld", s[24 + k]);
             fprintf(stderr, "\n");
+            for (int k = 0; k < 8; k++) {
+                if (!s[16 + k]) continue;
+                fprintf(stderr, "[amc k_clusters_wide %-16s %7lld waves, %5.1f us]", cn[k], s[16 + k], s[8 + k] / (double)s[16 + k] / 100.0);
+                for (int e = 0; e < 11; e++) fprintf(stderr, " %s %.2f", pn[e], s[32 + 12 * k + e] / (double)s[16 + k] / 100.0);
+                fprintf(stderr, "\n");
+            }
         }
-        if (h[71]) fprintf(stderr, "[pair waves that lived > 20 us (%lld), us] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f\n", h[71], h[64] / (double)h[71] / 100.0, h[65] / (double)h[71] / 100.0, h[66] / (double)h[71] / 100.0, h[67] / (double)h[71] / 100.0, h[68] / (double)h[71] / 100.0, h[69] / (double)h[71] / 100.0, h[70] / (double)h[71] / 100.0);
-        fprintf(stderr, "[amc k_clusters_wide phases, us per working wave] graph %.2f walk %.2f reserve %.2f pairs %.2f clusters %.2f publish %.2f probe %.2f | waves %lld | launch span (first wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us; launches with a re-emulation: %lld, their span %.2f us, the others' %.2f us\n",
-                h[16] / w / 100.0, h[17] / w / 100.0, h[18] / w / 100.0, h[19] / w / 100.0, h[20] / w / 100.0, h[21] / w / 100.0, h[22] / w / 100.0, h[31],
-                h[27] / n / 100.0, h[26] / n / 100.0, h[30] / 100.0, h[25], h[25] ? h[23] / (double)h[25] / 100.0 : 0.0,
-                (n - h[25]) > 0 ? (h[27] - h[23]) / (n - h[25]) / 100.0 : 0.0);
     }
     for (int k = 0; k < AMC_K_COUNT; k++) {
         if (total_ms) total_ms[k] = c->k_ms[k];

@@ -236,7 +236,8 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
     // speculative: record and state of my first candidate (valid memory for any k below the capacity)
     const int k_first = wave_id * per + lane;
     int4 c4_first = make_int4(0, 0, -1, -1);
-    if (lane < per && k_first < W.max_cand) c4_first = W.cand4[k_first];
+    unsigned int mark_first = 0;
+    if (lane < per && k_first < W.max_cand) { c4_first = W.cand4[k_first]; mark_first = W.cand_mark[k_first]; }
     int ncand = (int)A.O.cnt->cand_count;
     if (ncand > W.max_cand) ncand = W.max_cand;
     if (wave_id == 0 && lane == 0) { wc->active = 1; wc->ncand = ncand; }
@@ -251,8 +252,8 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
 
     // phase timers (diagnostic, AMC_DEBUG_RESOLVE=1): kept in registers and added to the debug buffer when the wave ends —
     // an atomic per stamp would sit in the wave's memory queue in front of the loads it is supposed to time
-    long long t_last = (A.dbg && lane == 0) ? wall_clock64() : 0;
-    long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    long long t_last = t_enter__;
+    long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define CW_STAMP(slot)                                                                     \
     do {                                                                                   \
         if (timed__) {                                                                     \
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         }                                                                                  \
     } while (0)
     const bool timed__ = A.dbg && lane == 0 && wave_id * per < ncand;     // waves with work in their first pass
+    if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(7); }      // entry -> candidate count and my first candidate have arrived
     int cat__ = 0;
     for (int k0 = wave_id * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
@@ -270,15 +272,25 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         // ---- 1. my candidate and the graph around it -----------------------------------------------------------------
         int4 c4 = make_int4(0, 0, -1, -1);
         int head_i = -1, head_j = -1;
-        amc_particle pre_j, pre_i;          // state of both particles, requested together with the graph heads (one round trip)
+        amc_particle pre_j, pre_i;          // state of both particles
+        bool iso = false;
         if (valid) {
             c4 = (k == k_first) ? c4_first : W.cand4[k];
+            const unsigned int mk = (k == k_first) ? mark_first : W.cand_mark[k];
+            // alone on both particles: nobody before it in either list, nobody displaced it from either head (the detect
+            // kernel marks the displaced candidate) — decided from candidate-indexed words only
+            iso = c4.z < 0 && c4.w < 0 && mk != A.sweep_epoch;
+            if (!iso) {                     // part of a larger component: the walk below starts at the particles' heads
+                head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
+                head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
+            }
+        }
+        CW_STAMP(9);
+        if (valid) {
             pre_j = rs_load_particle(A.S, c4.y);
             pre_i = rs_load_particle(A.S, c4.x);
-            head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
-            head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
         }
-        const bool iso = valid && head_i == k && c4.z < 0 && head_j == k && c4.w < 0;
+        if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(8); }      // -> both particles (and the heads) have arrived
         CW_STAMP(0);
         bool owner = valid && !iso;
         int nm = 2, nc = 1;
@@ -430,7 +442,6 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
             // was never published: it is simply dropped), unless it has had its turns: then the particles still get their
             // slots and the ordered workgroup takes over
             if (!__ballot(L.redo[lane] != 0)) break;
-            if (A.dbg && lane == 0) A.dbg[24] = 1;          // (diagnostic: this launch has a wave that emulates again)
             if (timed__ && L.redo[0]) cat__ |= 4;
             if (iter + 1 == CW_ITERS || L.nitems >= CW_ITEMS - 8) {
                 if (L.redo[lane]) {
@@ -483,22 +494,20 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
             }
         }
         rs_wave_sync();
-    }
-    if (A.dbg && lane == 0) {       // span of the launch as the device sees it: first wave in, last wave out
-        atomicMin((unsigned long long *)&A.dbg[28], (unsigned long long)t_enter__);
-        atomicMax((unsigned long long *)&A.dbg[29], (unsigned long long)wall_clock64());
+        CW_STAMP(10);
     }
     if (timed__) {
-        atomicMax((unsigned long long *)&A.dbg[30], (unsigned long long)(wall_clock64() - t_enter__));
-        atomicAdd((unsigned long long *)&A.dbg[32 + 2 * cat__], (unsigned long long)(wall_clock64() - t_enter__));
-        atomicAdd((unsigned long long *)&A.dbg[33 + 2 * cat__], 1ULL);
-        if (cat__ == 0) { int b = (int)((wall_clock64() - t_enter__) / 250); if (b > 15) b = 15; atomicAdd((unsigned long long *)&A.dbg[48 + b], 1ULL); }
-        atomicAdd((unsigned long long *)&A.dbg[31], 1ULL);
-        for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[16 + e], (unsigned long long)t_acc[e]);
-        if (cat__ == 0 && wall_clock64() - t_enter__ > 2000) {       // the slow pair waves (> 20 us): where did they spend it?
-            for (int e = 0; e < 7; e++) atomicAdd((unsigned long long *)&A.dbg[64 + e], (unsigned long long)t_acc[e]);
-            atomicAdd((unsigned long long *)&A.dbg[71], 1ULL);
-        }
+        // Every wave keeps its figures in 64 words of its own (plain read-modify-write: a wave id occurs once per launch and
+        // launches are serial).  The first version added them to shared words with atomics: a few hundred waves hitting one
+        // line jam that memory channel for microseconds — it showed up as a 4 us "stall" of whatever the OTHER waves did next.
+        long long *R = A.dbg + 128 + 128 * (long long)wave_id;
+        const long long t_exit = wall_clock64(), life = t_exit - t_enter__;
+        R[0] = t_enter__; R[1] = t_exit; R[2] = A.sweep_epoch;          // (this launch: the ordered workgroup forms the span)
+        R[3] += 1;
+        if (life > R[4]) R[4] = life;
+        R[8 + cat__] += life; R[16 + cat__] += 1;                       // by kind of wave
+        for (int e = 0; e < 11; e++) R[32 + 12 * cat__ + e] += t_acc[e];
+        if (cat__ == 0) { int bk = (int)(life / 250); if (bk > 7) bk = 7; R[24 + bk] += 1; }
     }
 }
 

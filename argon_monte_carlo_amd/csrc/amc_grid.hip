@@ -51,6 +51,7 @@ struct amc_adj {
     int4 *sl_meta;
     int *sl_hits, *ev_gen;
     unsigned int epoch;
+    unsigned int *mark;
 };
 
 AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt, const amc_adj &D)
@@ -65,6 +66,11 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
             const unsigned long long oi = atomicExch(&D.head[hi], mine), oj = atomicExch(&D.head[lo], mine);
             r.z = ((unsigned int)(oi >> 32) == D.epoch) ? (int)(unsigned int)(oi & 0xffffffffULL) : -1;
             r.w = ((unsigned int)(oj >> 32) == D.epoch) ? (int)(unsigned int)(oj & 0xffffffffULL) : -1;
+            // the candidates my exchanges displaced are no longer alone on their particle: told in a candidate-indexed word,
+            // so that the lane of an ISOLATED pair (99 %) never has to read the particle-indexed heads (a sparsely touched
+            // N-sized array: its translation misses made that one load 4.3 us of the wide kernel's 12 us chain)
+            if (r.z >= 0) D.mark[r.z] = D.epoch;
+            if (r.w >= 0) D.mark[r.w] = D.epoch;
         }
         D.rec[k] = r;
         D.sd[k] = make_int4(-1, -1, 0, 0);      // (slot of i, slot of j, done by the wide kernel, -)
@@ -208,7 +214,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
     // workgroup itself, a large one by the wide commit kernel
     c->plan_split = !c->allpairs && !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
     D.head = c->allpairs ? nullptr : c->W.adj_head; D.rec = c->W.cand4; D.sd = c->W.cand_s; D.epoch = c->sweep_epoch;
-    D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen;
+    D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen; D.mark = c->W.cand_mark;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->detect_ap) {
         const int ntiles = (int)((n + AP_T - 1) / AP_T);

@@ -81,6 +81,8 @@ struct amc_resolve_ws {
     // candidates: cand4[k] = (i, j, next candidate in i's list, next candidate in j's list), i > j (particle indices);
     // cand_s[k] = (slot of i, slot of j, done by the wide kernel, -)
     int4 *cand4, *cand_s;
+    unsigned int *cand_mark;  // [max_cand] == sweep epoch: a later candidate of this sweep shares a particle with this one (set by the
+                              // detect kernel when its exchange on the particle's graph head returns this candidate)
     int max_cand;
     unsigned long long *adj_head;   // [n] (sweep epoch << 32) | last candidate pushed that touches the particle
     int *slot_of;             // [n] particle -> slot or -1

@@ -55,10 +55,17 @@ template <int GEOM, int MODE>
 __global__ __launch_bounds__(RS_T) void k_resolve(rs_args A)
 {
     long long t_last = (A.dbg && threadIdx.x == 0) ? wall_clock64() : 0;
-    if (A.dbg && threadIdx.x == 0 && MODE == 0 && A.dbg[29] > 0) {      // span of the wide kernel's launch (first wave in -> last wave out)
-        A.dbg[27] += A.dbg[29] - A.dbg[28]; A.dbg[26] += t_last - A.dbg[29];
-        if (A.dbg[24]) { A.dbg[23] += A.dbg[29] - A.dbg[28]; A.dbg[25] += 1; A.dbg[24] = 0; }
-        A.dbg[28] = 0x7fffffffffffffffLL; A.dbg[29] = 0;
+    if (A.dbg && MODE == 0 && A.wide_plan) {        // span of the wide kernel's launch: first working wave in -> last one out
+        __shared__ unsigned long long s_in, s_out;
+        if (threadIdx.x == 0) { s_in = ~0ULL; s_out = 0ULL; }
+        __syncthreads();
+        for (int w = threadIdx.x; w < 512; w += RS_T) {
+            const long long *R = A.dbg + 128 + 128 * (long long)w;
+            if (R[2] == (long long)A.sweep_epoch) { atomicMin(&s_in, (unsigned long long)R[0]); atomicMax(&s_out, (unsigned long long)R[1]); }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_out > 0) { A.dbg[27] += (long long)(s_out - s_in); A.dbg[26] += t_last - (long long)s_out; A.dbg[25] += 1; }
+        __syncthreads();
     }
     __shared__ rs_shared sh;
     __shared__ int wide_ns;             // slots made by the wide cluster kernel in this sweep, -1 if it did not run
