@@ -46,6 +46,8 @@ SIGNATURES = {
     "amc_temp_device_results": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_temp_device_sums": (C.c_int, [_ctx, _dp, C.POINTER(C.c_int32)]),
     "amc_temp_device_draws": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "amc_host_directions": (C.c_int, [C.POINTER(C.c_uint32), _i32p, C.POINTER(C.c_uint32), _i32p, _dp, _u8p, C.c_int64, C.c_double,
+                                      C.c_double, C.c_int, C.c_void_p, _dp]),
     "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),
     "amc_drain_paths": (C.c_int, [_ctx, C.POINTER(AmcPathRecord), C.c_size_t, C.POINTER(C.c_size_t)]),

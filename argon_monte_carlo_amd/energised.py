@@ -20,14 +20,47 @@ HOT_CASES = (4, 6, 8)                   # contribute to energy_change_hot_in_ste
 GAP_CASE = 5                            # momentum only (Temp:722-723)
 
 
+def _numpy_ddot():
+    """cblas_ddot of the BLAS this NumPy loaded, as (dot_kind, address) for amc_host_directions — np.dot of two
+    float64[3] IS that function, so handing it over keeps the dot product NumPy's own.  None if it cannot be found."""
+    import ctypes as C
+    try:
+        with open("/proc/self/maps") as fh:
+            paths = sorted({ln.split()[-1] for ln in fh if "blas" in ln.lower() and ".so" in ln})
+    except OSError:
+        return None
+    for path in paths:
+        try:
+            lib = C.CDLL(path)
+        except OSError:
+            continue
+        for name, kind in (("scipy_cblas_ddot64_", 2), ("cblas_ddot64_", 2), ("scipy_cblas_ddot", 3), ("cblas_ddot", 3)):
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                continue
+            return kind, C.cast(fn, C.c_void_p).value, lib         # (the library object keeps the mapping alive)
+    return None
+
+
 class DirectionSampler:
     """random_components / random_inbounds_direction (Temp:119-141) on the given generators.
-    Defaults: the module-level ``np.random`` and ``random`` streams, exactly what the reference uses."""
+    Defaults: the module-level ``np.random`` and ``random`` streams, exactly what the reference uses.
 
-    def __init__(self, np_rng=None, py_rng=None):
+    ``sample_case`` draws the directions of all hits of one case.  When both generators are Mersenne Twisters whose state
+    can be taken and put back (``np.random`` / ``RandomState``, ``random`` / ``random.Random``) it does so in the library's
+    host helper ``amc_host_directions`` — the same draws from the same streams, 40 times faster than three library calls
+    and a small ndarray per attempt — after that helper has reproduced the per-hit calls bit for bit, generator states
+    included, on this interpreter's NumPy / libm / BLAS (``fast_path()``); otherwise it is the per-hit loop."""
+
+    _fast = None            # (dot_kind, dot_fn, keep-alive) once the self-test has passed, False when it has failed
+
+    def __init__(self, np_rng=None, py_rng=None, fast=True):
         self.np_rng = np.random if np_rng is None else np_rng
         self.py_rng = _py_random if py_rng is None else py_rng
         self.cos85 = cos(85 * pi / 180)
+        self.want_fast = fast
+        self._session = None
 
     def random_components(self, r):
         costheta = self.np_rng.uniform(low=-1.0, high=1.0)                   # Temp:120
@@ -51,6 +84,128 @@ class DirectionSampler:
             break
         return new_direction
 
+    # ---- all hits of a case at once -------------------------------------------------------------------------------------
+    def _states_borrowable(self):
+        npr, pyr = self.np_rng, self.py_rng
+        ok_np = npr is np.random or isinstance(npr, np.random.RandomState)
+        ok_py = pyr is _py_random or type(pyr) is _py_random.Random
+        if not (ok_np and ok_py):
+            return False
+        try:
+            return npr.get_state()[0] == "MT19937"
+        except Exception:
+            return False
+
+    @classmethod
+    def fast_path(cls):
+        """(dot_kind, dot_fn) of a helper configuration that reproduces the per-hit library calls, or False.  Decided once
+        per process by running both on equally seeded generators over hits with all sorts of normals."""
+        if cls._fast is not None:
+            return cls._fast
+        cls._fast = False
+        try:
+            from . import _lib
+            lib = _lib.load()
+        except Exception:
+            return False
+        rs = np.random.RandomState(20240611)
+        normals = rs.standard_normal((1500, 3))
+        normals /= np.linalg.norm(normals, axis=1)[:, None]
+        normals[::7] = (0.0, 0.0, 1.0)
+        normals[1::7] = (0.0, 0.0, -1.0)
+        normals[2::7, 2] = 0.0                                  # side walls: radial normals
+        normals[2::7] /= np.linalg.norm(normals[2::7], axis=1)[:, None]
+        ok = np.ones(len(normals), dtype=np.uint8)
+        ok[5::11] = 0
+        ref = cls(np.random.RandomState(4711), _py_random.Random(4711), fast=False)
+        want = ref._sample_loop(normals, ok)
+        want_np, want_py = ref.np_rng.get_state(), ref.py_rng.getstate()
+        blas = _numpy_ddot()
+        for cand in ([blas] if blas else []) + [(0, None, None), (1, None, None)]:
+            s = cls(np.random.RandomState(4711), _py_random.Random(4711))
+            try:
+                got = s._sample_helper(lib, cand[0], cand[1], normals, ok)
+            except Exception:
+                continue
+            got_np, got_py = s.np_rng.get_state(), s.py_rng.getstate()
+            if (np.array_equal(got.view(np.uint64), want.view(np.uint64)) and np.array_equal(got_np[1], want_np[1])
+                    and got_np[2] == want_np[2] and got_py == want_py):
+                cls._fast = cand
+                break
+        return cls._fast
+
+    def _sample_loop(self, normals, ok):
+        n = len(normals)
+        dirs = np.zeros((n, 3))
+        for k in range(n):
+            if ok[k]:                                       # (else: the reference's try-block fails before any draw)
+                dirs[k] = self.random_inbounds_direction(np.array(normals[k]))
+        return dirs
+
+    def _take_states(self):
+        st = self.np_rng.get_state()
+        ver, internal, gauss = self.py_rng.getstate()
+        import ctypes as C
+        return {"np_key": np.array(st[1], dtype=np.uint32), "np_pos": C.c_int32(int(st[2])), "np_rest": (st[3], st[4]),
+                "py_key": np.array(internal[:-1], dtype=np.uint32), "py_pos": C.c_int32(int(internal[-1])), "py_rest": (ver, gauss)}
+
+    def _put_states(self, S):
+        self.np_rng.set_state(("MT19937", S["np_key"], int(S["np_pos"].value)) + tuple(S["np_rest"]))
+        self.py_rng.setstate((S["py_rest"][0], tuple(S["py_key"].tolist()) + (int(S["py_pos"].value),), S["py_rest"][1]))
+
+    def _sample_helper(self, lib, dot_kind, dot_fn, normals, ok):
+        import ctypes as C
+        normals = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
+        ok8 = np.ascontiguousarray(ok, dtype=np.uint8)
+        n = len(normals)
+        dirs = np.zeros((n, 3))
+        S = self._session if self._session is not None else self._take_states()
+        try:
+            rc = lib.amc_host_directions(S["np_key"].ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(S["np_pos"]),
+                                         S["py_key"].ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(S["py_pos"]),
+                                         normals.ctypes.data_as(C.POINTER(C.c_double)), ok8.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                         n, self.cos85, pi, int(dot_kind), C.c_void_p(dot_fn), dirs.ctypes.data_as(C.POINTER(C.c_double)))
+        finally:
+            if self._session is None:
+                self._put_states(S)
+        if rc != 0:
+            raise RuntimeError(f"amc_host_directions failed ({rc})")
+        return dirs
+
+    def session(self):
+        """Context manager around a step's cases: the generator states are taken once and put back at the end (taking and
+        restoring CPython's 625-word tuple costs as much as a hundred hits).  Nothing else may draw from the two
+        generators inside."""
+        sampler = self
+
+        class _Session:
+            def __enter__(self_inner):
+                if sampler.want_fast and sampler._session is None and sampler._states_borrowable() and sampler.fast_path():
+                    sampler._session = sampler._take_states()
+                    self_inner.mine = True
+                else:
+                    self_inner.mine = False
+                return sampler
+
+            def __exit__(self_inner, *exc):
+                if self_inner.mine:
+                    S, sampler._session = sampler._session, None
+                    sampler._put_states(S)
+                return False
+
+        return _Session()
+
+    def sample_case(self, normals, ok):
+        """Directions [n, 3] for the hits of one case (zero rows where ``ok`` is false), in hit order."""
+        if len(normals) == 0:
+            return np.zeros((0, 3))
+        if self.want_fast and self._states_borrowable():
+            cfg = self.fast_path()
+            if cfg:
+                from . import _lib
+                return self._sample_helper(_lib.load(), cfg[0], cfg[1], normals, ok)
+        return self._sample_loop(normals, ok)
+
 
 class SurfaceEnergies:
     """surface_energy_cold / surface_energy_hot (Temp:80-84) and surface_energy_gap(z) (Temp:143-152) via mpmath,
@@ -73,12 +228,89 @@ class SurfaceEnergies:
         self.hot_mpf = 9 * self.t_hot * self.n_graphene * self.boltzman * (self.t_hot / self.t_debye_graphene) ** 3 * q_hot
         self.cold, self.hot = float(self.cold_mpf), float(self.hot_mpf)
 
+    # ---- several gap energies at once ---------------------------------------------------------------------------------
+    # One mpmath.quad costs 0.7-1.5 ms of pure-Python multiprecision arithmetic and a step at N = 1e6 has about five gap
+    # hits: half of the energised step's host time.  The integrals are independent and consume no random numbers, so the
+    # hits of a case are spread over forked worker processes running this very method — same code, same mpmath, same
+    # bits.  (fork without exec: the children never touch the GPU and leave through os._exit; AMC_GAP_WORKERS=0 turns
+    # it off, =k sets the number of workers.)
+    _pool = None
+    _pool_owner = None
+
+    def _workers_wanted(self):
+        import os
+        v = os.environ.get("AMC_GAP_WORKERS")
+        if v is not None:
+            try:
+                return max(0, int(v))
+            except ValueError:
+                return 0
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        return min(8, cores - 1) if cores > 2 else 0
+
+    def _get_pool(self):
+        cls = SurfaceEnergies
+        if cls._pool is not None and cls._pool_owner is self:
+            return cls._pool
+        if cls._pool is not None:
+            cls._pool.terminate()
+            cls._pool = None
+        nw = self._workers_wanted()
+        if nw < 2:
+            return None
+        import atexit
+        import multiprocessing as mp
+        global _WORKER_ENERGIES
+        _WORKER_ENERGIES = self                      # inherited by the forked workers
+        try:
+            cls._pool = mp.get_context("fork").Pool(nw)
+        except (OSError, ValueError):
+            cls._pool = None
+            return None
+        cls._pool_owner = self
+        atexit.register(cls._shutdown_pool)
+        return cls._pool
+
+    @classmethod
+    def _shutdown_pool(cls):
+        if cls._pool is not None:
+            try:
+                cls._pool.terminate()
+            except Exception:
+                pass
+            cls._pool = None
+            cls._pool_owner = None
+
+    def gap_many(self, z_values):
+        """surface_energy_gap for every contact height of a case, in order (Temp:143-152 per hit)."""
+        zs = [float(z) for z in z_values]
+        if len(zs) >= 2:
+            pool = self._get_pool()
+            if pool is not None:
+                try:
+                    return pool.map(_gap_in_worker, zs, chunksize=1)
+                except Exception:
+                    SurfaceEnergies._shutdown_pool()            # (a dead worker: fall back to this process for good)
+                    import os
+                    os.environ["AMC_GAP_WORKERS"] = "0"
+        return [self.gap(z) for z in zs]
+
     def gap(self, z_value):
         z_value = float(z_value)
         m = (self.t_cold - self.t_hot) / self.gap_height                                   # Temp:144
         t_gap = m * (z_value - self.gap_bottom_height) + self.t_hot                        # Temp:145
         q = self._quad(self._integrand, [0, self.t_debye_alumina / t_gap])                 # Temp:148
         return float(9 * t_gap * self.n_alumina * self.boltzman * (t_gap / self.t_debye_alumina) ** 3 * q)   # Temp:152
+
+
+_WORKER_ENERGIES = None
+
+
+def _gap_in_worker(z):
+    return _WORKER_ENERGIES.gap(z)
 
 
 def sequential_sum(values):
@@ -103,34 +335,58 @@ def drive_energised_cases(hooks, sampler, energies):
 
     ``hooks.wall_hits(case)`` -> (idx, normals[n,3], contact_z[n], ok[n]) in ascending particle index;
     ``hooks.wall_apply(case, dirs[n,3], Es[n])`` -> (dpz[n], dE[n]).  Returns (momentum, energy_cold, energy_hot,
-    had_momentum, had_cold, had_hot) for the step, accumulated in the reference's order."""
+    had_momentum, had_cold, had_hot) for the step, accumulated in the reference's order.
+
+    Per hit the reference draws the direction first and evaluates the surface energy second (Temp:367-368 and
+    alike); the energy consumes no random numbers, so all directions of a case are drawn first (``sample_case``) and the
+    gap energies of the case are evaluated together afterwards (``gap_many``: worker processes when there are several)."""
     mom = cold = hot = 0
     had_m = had_c = had_h = False
-    for case in CASES:
-        idx, normals, contact_z, ok = hooks.wall_hits(case)
-        n = len(idx)
-        if n == 0:
-            continue
-        dirs = np.zeros((n, 3))
-        Es = np.zeros(n)
-        for k in range(n):
-            if not ok[k]:
-                continue                                   # the reference's try-block fails before any RNG draw
-            dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
-            Es[k] = (energies.gap(contact_z[k]) if case == GAP_CASE else
-                     energies.cold if case in COLD_CASES else energies.hot)
-        dpz, dE = hooks.wall_apply(case, dirs, Es)
-        good = [k for k in range(n) if ok[k]]
-        m_case = sequential_sum(dpz[k] for k in good)
-        mom = mom + m_case
-        had_m = had_m or len(good) > 0
-        if case in COLD_CASES:
-            cold = cold + sequential_sum(dE[k] for k in good)
-            had_c = had_c or len(good) > 0
-        elif case in HOT_CASES:
-            hot = hot + sequential_sum(dE[k] for k in good)
-            had_h = had_h or len(good) > 0
+    with (sampler.session() if hasattr(sampler, "session") else _NoSession(sampler)):
+        for case in CASES:
+            idx, normals, contact_z, ok = hooks.wall_hits(case)
+            n = len(idx)
+            if n == 0:
+                continue
+            if hasattr(sampler, "sample_case"):
+                dirs = sampler.sample_case(normals, ok)
+            else:
+                dirs = np.zeros((n, 3))
+                for k in range(n):
+                    if ok[k]:                               # (else: the reference's try-block fails before any RNG draw)
+                        dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
+            good = [k for k in range(n) if ok[k]]
+            Es = np.zeros(n)
+            if case == GAP_CASE:
+                if hasattr(energies, "gap_many"):
+                    Es[good] = energies.gap_many([contact_z[k] for k in good])
+                else:
+                    for k in good:
+                        Es[k] = energies.gap(contact_z[k])
+            else:
+                Es[good] = energies.cold if case in COLD_CASES else energies.hot
+            dpz, dE = hooks.wall_apply(case, dirs, Es)
+            m_case = sequential_sum(dpz[k] for k in good)
+            mom = mom + m_case
+            had_m = had_m or len(good) > 0
+            if case in COLD_CASES:
+                cold = cold + sequential_sum(dE[k] for k in good)
+                had_c = had_c or len(good) > 0
+            elif case in HOT_CASES:
+                hot = hot + sequential_sum(dE[k] for k in good)
+                had_h = had_h or len(good) > 0
     return mom, cold, hot, had_m, had_c, had_h
+
+
+class _NoSession:
+    def __init__(self, sampler):
+        self.sampler = sampler
+
+    def __enter__(self):
+        return self.sampler
+
+    def __exit__(self, *exc):
+        return False
 
 
 def device_rng_config(consts, seed, n_gl=32):

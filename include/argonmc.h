@@ -222,6 +222,20 @@ int amc_paths_pending(amc_ctx *ctx, size_t *n);
 int amc_histograms(amc_ctx *ctx, uint64_t *counts, uint64_t *n_paths_total);
 int amc_reset_outputs(amc_ctx *ctx);
 
+/* Host-only helper of the hand-over above (no GPU, no context): the re-emission directions of one case's hits —
+ * random_components / random_inbounds_direction (Temp:119-141) — drawn from the reference's two Mersenne Twisters, whose
+ * states come in NumPy's / CPython's layout (uint32 key[624] + position 0..624: np.random.get_state()[1:3],
+ * random.getstate()[1]) and go back advanced exactly as the per-hit library calls would have left them.
+ * normal_xyz [n][3]; ok == NULL or ok[k] == 0: no draw, zero direction (the reference fails before it draws, Temp:367);
+ * cos85 = cos(85 pi / 180), pi = math.pi as the caller's Python computes them; dir_xyz [n][3] out.
+ * dot_kind selects how dot(direction, normal) is formed — it must equal np.dot of two float64[3] on the caller's NumPy:
+ *   0: ((x0 y0) + x1 y1) + x2 y2   1: fma(x2, y2, fma(x1, y1, x0 y0))
+ *   2: dot_fn = cblas_ddot with 64-bit integers   3: dot_fn = cblas_ddot with 32-bit integers
+ * (argon_monte_carlo_amd/energised.py takes the BLAS NumPy itself loaded and checks the whole function against the
+ * per-hit library calls before it uses it). */
+int amc_host_directions(uint32_t *np_key, int32_t *np_pos, uint32_t *py_key, int32_t *py_pos, const double *normal_xyz,
+                        const uint8_t *ok, int64_t n, double cos85, double pi, int dot_kind, void *dot_fn, double *dir_xyz);
+
 /* ---- opt-in, NON-PARITY mode: the energised cases entirely on the device ----------------------------------
  * The reference draws the re-emission direction of every hit from two Mersenne Twisters in particle order with a
  * rejection loop (Temp:119-141) and integrates the gap wall's surface energy with mpmath (Temp:143-152); reproducing

@@ -110,6 +110,109 @@ def test_direction_sampler_sign_draw_equals_numpy_choice():
     assert a.get_state()[2] == b.get_state()[2] and np.array_equal(a.get_state()[1], b.get_state()[1])
 
 
+def _random_normals(n, seed):
+    rs = np.random.RandomState(seed)
+    nm = rs.standard_normal((n, 3))
+    nm /= np.linalg.norm(nm, axis=1)[:, None]
+    nm[::5] = (0.0, 0.0, 1.0)                   # the planes of cases 3, 4, 6
+    nm[1::5] = (0.0, 0.0, -1.0)
+    nm[2::5, 2] = 0.0                           # the gap's side wall: radial normals
+    nm[2::5] /= np.linalg.norm(nm[2::5], axis=1)[:, None]
+    return nm
+
+
+def test_host_direction_helper_equals_the_library_calls():
+    """amc_host_directions (the C helper behind DirectionSampler.sample_case) against the per-hit calls of np.random /
+    random / math / np.dot it replaces (Temp:119-141): same directions bit for bit, and both Mersenne Twisters left
+    exactly where the library calls leave them — with RandomState / random.Random instances and with the module-level
+    generators the reference uses, inside a session and outside."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler
+    assert DirectionSampler.fast_path(), "the helper did not reproduce the library calls on this interpreter"
+    nm = _random_normals(700, 1)
+    ok = np.ones(len(nm), dtype=np.uint8)
+    ok[3::13] = 0
+    slow = DirectionSampler(np.random.RandomState(17), random.Random(17), fast=False)
+    fast = DirectionSampler(np.random.RandomState(17), random.Random(17))
+    a1, b1 = slow.sample_case(nm, ok), fast.sample_case(nm, ok)
+    assert np.array_equal(a1.view(np.uint64), b1.view(np.uint64))
+    assert not a1[ok == 0].any() and (np.abs(np.linalg.norm(a1[ok == 1], axis=1) - 1) < 1e-12).all()
+    with fast.session():                        # a step: several cases on one borrowed state
+        b2 = fast.sample_case(nm[:40], ok[:40])
+        b3 = fast.sample_case(nm[40:45], ok[40:45])
+        assert len(fast.sample_case(nm[:0], ok[:0])) == 0
+    a2, a3 = slow.sample_case(nm[:40], ok[:40]), slow.sample_case(nm[40:45], ok[40:45])
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    sa, sb = slow.np_rng.get_state(), fast.np_rng.get_state()
+    assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    assert slow.py_rng.getstate() == fast.py_rng.getstate()
+    # rejections happened (|d.n| < cos 85 deg redraws) and flips happened
+    assert (np.einsum("ij,ij->i", a1, nm)[ok == 1] >= slow.cos85).all()
+    # the module-level streams, seeded like the reference seeds them (Temp:108-109)
+    np.random.seed(17); random.seed(17)
+    c1 = DirectionSampler(fast=False).sample_case(nm[:90], ok[:90])
+    tail1 = (np.random.uniform(), random.random(), np.random.randint(0, 2))
+    np.random.seed(17); random.seed(17)
+    d1 = DirectionSampler().sample_case(nm[:90], ok[:90])
+    tail2 = (np.random.uniform(), random.random(), np.random.randint(0, 2))
+    assert np.array_equal(c1, d1) and tail1 == tail2
+
+
+def test_host_direction_helper_crosses_a_twister_refill():
+    """624 words per refill, 3 + 2 words per attempt: long cases cross many refills of both generators; positions 0 and
+    624 at entry are the edge cases of the state layout."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler
+    nm = _random_normals(4000, 2)
+    ok = np.ones(len(nm), dtype=np.uint8)
+    for burn in (0, 1, 623, 624, 625):
+        slow = DirectionSampler(np.random.RandomState(99), random.Random(99), fast=False)
+        fast = DirectionSampler(np.random.RandomState(99), random.Random(99))
+        for s in (slow, fast):
+            for _ in range(burn):
+                s.np_rng.randint(0, 2)          # one 32-bit word each
+                s.py_rng.getrandbits(32)
+        assert np.array_equal(slow.sample_case(nm, ok), fast.sample_case(nm, ok))
+        assert slow.py_rng.getstate() == fast.py_rng.getstate()
+        assert np.array_equal(slow.np_rng.get_state()[1], fast.np_rng.get_state()[1])
+        assert slow.np_rng.get_state()[2] == fast.np_rng.get_state()[2]
+
+
+def test_direction_sampler_falls_back_for_other_generators():
+    """Anything that is not one of the two Mersenne Twisters keeps the per-hit loop (no state to borrow)."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler
+
+    class Mine(random.Random):
+        pass
+
+    nm = _random_normals(20, 3)
+    ok = np.ones(20, dtype=np.uint8)
+    s = DirectionSampler(np.random.RandomState(1), Mine(1))
+    assert not s._states_borrowable()
+    ref = DirectionSampler(np.random.RandomState(1), random.Random(1), fast=False)
+    assert np.array_equal(s.sample_case(nm, ok), ref.sample_case(nm, ok))
+
+
+def test_gap_energies_in_worker_processes_equal_the_serial_ones(monkeypatch):
+    """SurfaceEnergies.gap_many spreads the mpmath integrals of a case over forked workers: same values, same order."""
+    from argon_monte_carlo_amd.energised import SurfaceEnergies
+    _, c = PR.pore_params(n=100, energised=True)
+    en = SurfaceEnergies(c)
+    z0 = c["open_air_height"] + c["hot_coating_height"]
+    zs = [z0 + f * c["gap_height"] for f in (0.0, 0.123, 0.5, 0.77, 1.0)]
+    want = [en.gap(z) for z in zs]
+    monkeypatch.setenv("AMC_GAP_WORKERS", "3")
+    try:
+        assert en.gap_many(zs) == want
+        assert SurfaceEnergies._pool is not None
+        assert en.gap_many(zs[:1]) == want[:1] and en.gap_many([]) == []
+    finally:
+        SurfaceEnergies._shutdown_pool()
+    monkeypatch.setenv("AMC_GAP_WORKERS", "0")
+    assert en.gap_many(zs) == want and SurfaceEnergies._pool is None
+
+
 def test_philox_reference_known_answers():
     """tests/philox_ref.py against the known-answer vectors of the Random123 distribution (kat_vectors, philox4x32 10)."""
     from tests.philox_ref import philox4x32_10
