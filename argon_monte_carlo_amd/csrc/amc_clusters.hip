@@ -219,7 +219,7 @@ AMC_DEV void cw_candidate_slots(const amc_resolve_ws &W, cw_lds &L, int own, int
     W.cand_s[c] = make_int4(L.msl[own][ai], L.msl[own][aj], 1, 0);
 }
 
-template <int GEOM>
+template <int GEOM, bool DBG>
 __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kernarg)
 {
     RS_STAGE_ARGS(A);
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
     const int lane = threadIdx.x & 63;
     const int nwaves = gridDim.x * CW_WPB;
     const int wave_id = blockIdx.x * CW_WPB + (threadIdx.x >> 6);
-    const long long t_enter__ = A.dbg ? wall_clock64() : 0;
+    long long *const dbg__ = DBG ? A.dbg : nullptr;     // (the phase timers are compiled out of the product's instantiation)
+    const long long t_enter__ = dbg__ ? wall_clock64() : 0;
     const int per = A.wide_per;         // candidates per wave and pass, fixed by the host: the first pass's candidate is
                                         // known before the sweep's candidate count has arrived
     // speculative: record and state of my first candidate (valid memory for any k below the capacity)
@@ -262,8 +263,8 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
             t_last = now__;                                                                \
         }                                                                                  \
     } while (0)
-    const bool timed__ = A.dbg && lane == 0 && wave_id * per < ncand;     // waves with work in their first pass
-    if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(7); }      // entry -> candidate count and my first candidate have arrived
+    const bool timed__ = DBG && dbg__ && lane == 0 && wave_id * per < ncand;     // waves with work in their first pass
+    if (DBG && dbg__) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(7); }      // entry -> candidate count and my first candidate have arrived
     int cat__ = 0;
     for (int k0 = wave_id * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
             pre_j = rs_load_particle(A.S, c4.y);
             pre_i = rs_load_particle(A.S, c4.x);
         }
-        if (A.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(8); }      // -> both particles (and the heads) have arrived
+        if (DBG && dbg__) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(8); }      // -> both particles (and the heads) have arrived
         CW_STAMP(0);
         bool owner = valid && !iso;
         int nm = 2, nc = 1;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         // Every wave keeps its figures in 64 words of its own (plain read-modify-write: a wave id occurs once per launch and
         // launches are serial).  The first version added them to shared words with atomics: a few hundred waves hitting one
         // line jam that memory channel for microseconds — it showed up as a 4 us "stall" of whatever the OTHER waves did next.
-        long long *R = A.dbg + 128 + 128 * (long long)wave_id;
+        long long *R = dbg__ + 128 + 128 * (long long)wave_id;
         const long long t_exit = wall_clock64(), life = t_exit - t_enter__;
         R[0] = t_enter__; R[1] = t_exit; R[2] = A.sweep_epoch;          // (this launch: the ordered workgroup forms the span)
         R[3] += 1;
@@ -521,9 +522,14 @@ int amc_clusters_wide_blocks(amc_ctx *c)
 hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
 {
     const int nb = amc_clusters_wide_blocks(c);
-    switch (c->P.geometry) {
-    case AMC_GEOM_CUBE: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE>), dim3((nb + CW_WPB - 1) / CW_WPB), dim3(64 * CW_WPB), 0, c->stream, A); break;
-    default: hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE>), dim3((nb + CW_WPB - 1) / CW_WPB), dim3(64 * CW_WPB), 0, c->stream, A); break;
+    const dim3 grid((nb + CW_WPB - 1) / CW_WPB), block(64 * CW_WPB);
+    const bool cube = c->P.geometry == AMC_GEOM_CUBE;
+    if (A.dbg) {        // AMC_DEBUG_RESOLVE=1: the instantiation with the phase timers
+        if (cube) hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE, true>), grid, block, 0, c->stream, A);
+        else hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE, true>), grid, block, 0, c->stream, A);
+    } else {
+        if (cube) hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE, false>), grid, block, 0, c->stream, A);
+        else hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE, false>), grid, block, 0, c->stream, A);
     }
     return hipGetLastError();
 }

@@ -25,27 +25,28 @@ def tm(name, t0):
     T[name] = T.get(name, 0.0) + time.perf_counter() - t0
 
 
-steps = 10
-t_all = time.perf_counter()
-for s in range(steps):
+steps, warm = 20, 5
+for s in range(steps + warm):
+    if s == warm:
+        T.clear(); hits = {k: 0 for k in CASES}; t_all = time.perf_counter()
     t0 = time.perf_counter(); e.temp_begin(c["dt"]); tm("temp_begin", t0)
+    t0 = time.perf_counter(); sess = sampler.session(); sess.__enter__(); tm("rng states", t0)
     for case in CASES:
         t0 = time.perf_counter(); idx, normals, cz, ok = e.wall_hits(case); tm("wall_hits", t0)
         n = len(idx); hits[case] += n
         if n == 0:
             continue
-        dirs = np.zeros((n, 3)); Es = np.zeros(n)
+        t0 = time.perf_counter(); dirs = sampler.sample_case(normals, ok); tm("rng", t0)
         t0 = time.perf_counter()
-        for k in range(n):
-            if ok[k]:
-                dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
-        tm("rng", t0)
-        t0 = time.perf_counter()
-        for k in range(n):
-            if ok[k]:
-                Es[k] = energies.gap(cz[k]) if case == GAP_CASE else (energies.cold if case in COLD_CASES else energies.hot)
+        good = [k for k in range(n) if ok[k]]
+        Es = np.zeros(n)
+        if case == GAP_CASE:
+            Es[good] = energies.gap_many([cz[k] for k in good])
+        else:
+            Es[good] = energies.cold if case in COLD_CASES else energies.hot
         tm("energies", t0)
         t0 = time.perf_counter(); e.wall_apply(case, dirs, Es); tm("wall_apply", t0)
+    t0 = time.perf_counter(); sess.__exit__(None, None, None); tm("rng states", t0)
     t0 = time.perf_counter(); e.temp_end(); tm("temp_end", t0)
 tot = time.perf_counter() - t_all
 print("total %.2f ms/step; hits per step by case: %s" % (tot / steps * 1e3, {k: v / steps for k, v in hits.items()}))
