@@ -781,7 +781,7 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
             }
             const double nl = h[25] > 0 ? (double)h[25] : 1.0;
             static const char *cn[8] = {"pair", "3-cluster", "4+-cluster", "not owner", "pair+again", "3-cluster+again", "4+-cluster+again", "not owner+again"};
-            static const char *pn[11] = {"graph", "walk", "reserve", "small: emulate + grid probe", "by the wave: emulate", "publish", "by the wave: grid probe", "first hop", "particles", "set-up", "overlay probe"};
+            static const char *pn[12] = {"graph", "walk", "reserve", "small: after emulate", "pair emulate | by the wave: emulate", "publish", "grid probe", "first hop", "particles", "set-up", "overlay probe", "small: prepare"};
             fprintf(stderr, "[amc k_clusters_wide] working waves %lld in %lld launches; launch span (first working wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us\n",
                     s[3], h[25], h[27] / nl / 100.0, h[26] / nl / 100.0, longest / 100.0);
             fprintf(stderr, "[pair-wave lifetimes, 2.5 us buckets]");
@@ -790,7 +790,7 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
             for (int k = 0; k < 8; k++) {
                 if (!s[16 + k]) continue;
                 fprintf(stderr, "[amc k_clusters_wide %-16s %7lld waves, %5.1f us]", cn[k], s[16 + k], s[8 + k] / (double)s[16 + k] / 100.0);
-                for (int e = 0; e < 11; e++) fprintf(stderr, " %s %.2f", pn[e], s[32 + 12 * k + e] / (double)s[16 + k] / 100.0);
+                for (int e = 0; e < 12; e++) fprintf(stderr, " %s %.2f", pn[e], s[32 + 12 * k + e] / (double)s[16 + k] / 100.0);
                 fprintf(stderr, "\n");
             }
         }

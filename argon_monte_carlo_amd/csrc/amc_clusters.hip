@@ -30,6 +30,7 @@
 // thinly as the launch allows: CW_BLOCKS one-wave workgroups, ceil(ncand / CW_BLOCKS) candidates per wave.
 #include <stdlib.h>
 
+#define RS_WAVE_SYNC_LDS_ONLY 1     // one wave per cluster, working set in LDS (see rs_wave_sync)
 #include "amc_resolve_dev.h"
 
 #define CW_MAXM 16          // particles of a component handled here
@@ -362,7 +363,9 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
                     cw_init_slot(W, sj, pj, lab, g + 1, true);
                     cw_init_slot(W, si, pi, lab, g + 1, true);
                     W.cand_s[k] = make_int4(si, sj, 1, 0);
+                    CW_STAMP(11);
                     rs_emulate_pair<GEOM>(A, wc, pre_j, pre_i, pj, pi, sj, si, &wd);
+                    CW_STAMP(4);
                 } else {
                     amc_particle q[3];
                     int pidx[3], slot[3];
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         R[3] += 1;
         if (life > R[4]) R[4] = life;
         R[8 + cat__] += life; R[16 + cat__] += 1;                       // by kind of wave
-        for (int e = 0; e < 11; e++) R[32 + 12 * cat__ + e] += t_acc[e];
+        for (int e = 0; e < 12; e++) R[32 + 12 * cat__ + e] += t_acc[e];
         if (cat__ == 0) { int bk = (int)(life / 250); if (bk > 7) bk = 7; R[24 + bk] += 1; }
     }
 }

@@ -659,9 +659,19 @@ AMC_DEV void rs_add_edge(const amc_resolve_ws &W, rs_shared *sh, int pa, int pb)
 // minimum), taking the membership masks of all members, finding the members' pore cells — is spread over the lanes here;
 // only the pair tests of a cell stay on lane 0.  Control flow is uniform; the lanes meet at wave-level fences.
 #define RS_COOP_MAX 11      // members: 55 pairs fit the 64 lanes
+// The lanes of ONE wave meet here after exchanging data.  A workgroup-scope fence waits for EVERY outstanding vector
+// memory operation of the wave (vmcnt(0)): right where the working set may live in global memory (the ordered
+// workgroup's large-sweep fallback), but a full memory round trip at every meeting point for a wave that has stores or
+// value-less atomics in flight and exchanges through LDS only — LDS operations of a wave execute in order, a compiler
+// barrier is all that takes.  k_clusters_wide (working set always in LDS) compiles with RS_WAVE_SYNC_LDS_ONLY: it
+// states the global-memory orderings it needs itself (write-through stores + s_waitcnt before the overlay pushes).
 AMC_DEV void rs_wave_sync()
 {
+#ifdef RS_WAVE_SYNC_LDS_ONLY
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 AMC_DEV int rs_wave_min_nonneg(int v)       // minimum over the lanes of the values >= 0, -1 if there is none
