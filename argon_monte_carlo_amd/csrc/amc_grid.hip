@@ -201,6 +201,70 @@ hipError_t amc_launch_bin(amc_ctx *c)
     return hipGetLastError();
 }
 
+// The same detector for large N: square tiles of AP2_T = 1024 particles, every thread keeps AP2_R = 4 particles i in
+// registers and walks the j-tile in LDS — a j read (four broadcast LDS loads) serves four pairs, the hit test only
+// accumulates a flag, and the (rare) chunk that raised it is walked again to push its pairs.
+// Arithmetic: d^2 = |ri|^2 + |rj|^2 - 2 ri.rj with the squared norms formed once per particle, so a pair costs three fused
+// multiply-adds and one comparison, t = |rj|^2 - 2 ri.rj < cr^2 - |ri|^2, instead of the 3 + 3 + 2 + 1 operations of the
+// direct form SURVEY 8d counts (9 flop per pair: the figure the roofline line is quoted in).  The expanded form cancels:
+// with coordinates taken relative to the grid origin its error is below 13 u R^2 (u = 2^-53, R^2 = squared diagonal of the
+// grid's extent), so the threshold is raised by 64 u R^2 — 7e-7 of cr^2 in the pore, 2e-9 in the cube at N = 1e5.  The
+// test only has to be a SUPERSET of the reference's sqrt(d^2) < collision_range: every candidate is re-tested exactly.
+#define AP2_T 1024
+#define AP2_R 4
+#define AP2_CHUNK 8
+__global__ __launch_bounds__(256) void k_detect_allpairs_tiled(const double *__restrict__ x, const double *__restrict__ y,
+                                                               const double *__restrict__ z, int n, int ntiles, double thr,
+                                                               double ox, double oy, double oz,
+                                                               int max_cand, amc_dev_counters *cnt, amc_adj D)
+{
+    int bi = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((long long)(bi + 1) * (bi + 2) / 2 <= (long long)blockIdx.x) bi++;
+    while ((long long)bi * (bi + 1) / 2 > (long long)blockIdx.x) bi--;
+    const int bj = (int)(blockIdx.x - (long long)bi * (bi + 1) / 2);
+    if (bi >= ntiles) return;
+    __shared__ double tx[AP2_T], ty[AP2_T], tz[AP2_T], tn[AP2_T];
+    const int j0 = bj * AP2_T;
+    for (int t = threadIdx.x; t < AP2_T; t += 256) {
+        const int jj = j0 + t;
+        const bool in = jj < n;
+        const double X = in ? x[jj] - ox : 0.0, Y = in ? y[jj] - oy : 0.0, Z = in ? z[jj] - oz : 0.0;
+        tx[t] = X; ty[t] = Y; tz[t] = Z;
+        tn[t] = in ? fma(Z, Z, fma(Y, Y, X * X)) : 1.0e300;        // (a padding particle never passes the test)
+    }
+    __syncthreads();
+    int ii[AP2_R];
+    double ax[AP2_R], ay[AP2_R], az[AP2_R], ti[AP2_R];
+#pragma unroll
+    for (int r = 0; r < AP2_R; r++) {
+        ii[r] = bi * AP2_T + r * 256 + (int)threadIdx.x;
+        const bool in = ii[r] < n;
+        const double X = in ? x[ii[r]] - ox : 0.0, Y = in ? y[ii[r]] - oy : 0.0, Z = in ? z[ii[r]] - oz : 0.0;
+        ax[r] = -2.0 * X; ay[r] = -2.0 * Y; az[r] = -2.0 * Z;
+        ti[r] = in ? thr - fma(Z, Z, fma(Y, Y, X * X)) : -1.0e300;
+    }
+    const bool diag = bi == bj;         // inside the diagonal tile only j < i counts
+    for (int k0 = 0; k0 < AP2_T; k0 += AP2_CHUNK) {
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < AP2_CHUNK; u++) {
+            const double jx = tx[k0 + u], jy = ty[k0 + u], jz = tz[k0 + u], jn = tn[k0 + u];
+#pragma unroll
+            for (int r = 0; r < AP2_R; r++) any |= fma(az[r], jz, fma(ay[r], jy, fma(ax[r], jx, jn))) < ti[r];
+        }
+        if (any) {
+            for (int u = 0; u < AP2_CHUNK; u++) {
+                const int j = j0 + k0 + u;
+                const double jx = tx[k0 + u], jy = ty[k0 + u], jz = tz[k0 + u], jn = tn[k0 + u];
+#pragma unroll
+                for (int r = 0; r < AP2_R; r++)
+                    if (fma(az[r], jz, fma(ay[r], jy, fma(ax[r], jx, jn))) < ti[r] && (diag ? j < ii[r] : true))
+                        amc_push_candidate(ii[r], j, max_cand, cnt, D);
+            }
+        }
+    }
+}
+
 hipError_t amc_launch_detect(amc_ctx *c)
 {
     const long long n = c->n;
@@ -217,11 +281,21 @@ hipError_t amc_launch_detect(amc_ctx *c)
     D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen; D.mark = c->W.cand_mark;
     amc_prof_begin(c, AMC_K_DETECT);
     if (c->detect_ap) {
-        const int ntiles = (int)((n + AP_T - 1) / AP_T);
-        const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
-        if (nblocks > 0)
-            hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
-                               c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
+        if (n >= 16 * AP2_T && c->G.ncells > 0) {       // enough tiles to fill the chip (and a grid, whose origin and extent it uses): the register-tiled form
+            const int ntiles = (int)((n + AP2_T - 1) / AP2_T);
+            const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
+            // coordinates relative to the grid origin; threshold raised by the cancellation bound of the expanded form
+            const double ex = c->G.gx * c->G.h, ey = c->G.gy * c->G.h, ez = c->G.gz * c->G.h;
+            const double thr = cr2i + 64.0 * 1.1102230246251565e-16 * (ex * ex + ey * ey + ez * ez);
+            hipLaunchKernelGGL(k_detect_allpairs_tiled, dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->S.x, c->S.y,
+                               c->S.z, (int)n, ntiles, thr, c->G.x0, c->G.y0, c->G.z0, c->W.max_cand, c->d_cnt, D);
+        } else {
+            const int ntiles = (int)((n + AP_T - 1) / AP_T);
+            const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
+            if (nblocks > 0)
+                hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
+                                   c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
+        }
     } else {
         hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
                            c->G.cr_probe, c->W.max_cand, c->d_cnt, D);
