@@ -211,9 +211,10 @@ hipError_t amc_launch_bin(amc_ctx *c)
 // grid's extent), so the threshold is raised by 64 u R^2 — 7e-7 of cr^2 in the pore, 2e-9 in the cube at N = 1e5.  The
 // test only has to be a SUPERSET of the reference's sqrt(d^2) < collision_range: every candidate is re-tested exactly.
 #define AP2_T 1024
-#define AP2_R 4
+#define AP2_R 4             // (8 per thread on 128-thread blocks measured 47 instead of 62 TFLOP/s)
+#define AP2_THREADS (AP2_T / AP2_R)
 #define AP2_CHUNK 8
-__global__ __launch_bounds__(256) void k_detect_allpairs_tiled(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(AP2_THREADS) void k_detect_allpairs_tiled(const double *__restrict__ x, const double *__restrict__ y,
                                                                const double *__restrict__ z, int n, int ntiles, double thr,
                                                                double ox, double oy, double oz,
                                                                int max_cand, amc_dev_counters *cnt, amc_adj D)
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void k_detect_allpairs_tiled(const double *__r
     if (bi >= ntiles) return;
     __shared__ double tx[AP2_T], ty[AP2_T], tz[AP2_T], tn[AP2_T];
     const int j0 = bj * AP2_T;
-    for (int t = threadIdx.x; t < AP2_T; t += 256) {
+    for (int t = threadIdx.x; t < AP2_T; t += AP2_THREADS) {
         const int jj = j0 + t;
         const bool in = jj < n;
         const double X = in ? x[jj] - ox : 0.0, Y = in ? y[jj] - oy : 0.0, Z = in ? z[jj] - oz : 0.0;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void k_detect_allpairs_tiled(const double *__r
     double ax[AP2_R], ay[AP2_R], az[AP2_R], ti[AP2_R];
 #pragma unroll
     for (int r = 0; r < AP2_R; r++) {
-        ii[r] = bi * AP2_T + r * 256 + (int)threadIdx.x;
+        ii[r] = bi * AP2_T + r * AP2_THREADS + (int)threadIdx.x;
         const bool in = ii[r] < n;
         const double X = in ? x[ii[r]] - ox : 0.0, Y = in ? y[ii[r]] - oy : 0.0, Z = in ? z[ii[r]] - oz : 0.0;
         ax[r] = -2.0 * X; ay[r] = -2.0 * Y; az[r] = -2.0 * Z;
@@ -287,7 +288,7 @@ hipError_t amc_launch_detect(amc_ctx *c)
             // coordinates relative to the grid origin; threshold raised by the cancellation bound of the expanded form
             const double ex = c->G.gx * c->G.h, ey = c->G.gy * c->G.h, ez = c->G.gz * c->G.h;
             const double thr = cr2i + 64.0 * 1.1102230246251565e-16 * (ex * ex + ey * ey + ez * ez);
-            hipLaunchKernelGGL(k_detect_allpairs_tiled, dim3((unsigned)nblocks), dim3(256), 0, c->stream, c->S.x, c->S.y,
+            hipLaunchKernelGGL(k_detect_allpairs_tiled, dim3((unsigned)nblocks), dim3(AP2_THREADS), 0, c->stream, c->S.x, c->S.y,
                                c->S.z, (int)n, ntiles, thr, c->G.x0, c->G.y0, c->G.z0, c->W.max_cand, c->d_cnt, D);
         } else {
             const int ntiles = (int)((n + AP_T - 1) / AP_T);
