@@ -523,6 +523,37 @@ def test_high_collision_rate_stresses_the_wide_cluster_kernel(Engine, O, kind, n
     eng.close()
 
 
+def test_allpairs_tiled_detector_in_the_pore_vs_oracle(Engine, O):
+    """The register-tiled all-pairs kernel tests d^2 in the expanded form |ri|^2 + |rj|^2 - 2 ri.rj, which cancels; its
+    threshold is raised by the cancellation bound of the grid's extent.  The pore is where that matters — 3.2 um long,
+    coordinates 10^4 collision ranges from the origin — so: detect_mode 2 at N = 20,000 with a raised cross-section
+    (two hundred collisions per step) against the oracle bit for bit, and against the binned detector."""
+    sigma = 3.6e-19 * 80.0
+    p, c = PR.pore_params(n=20_000, sigma=sigma)
+    init = IC.pore_ic(p, c, seed=43)
+    runs = {}
+    for mode in (2, 1):
+        p.detect_mode = mode
+        eng = Engine(p)
+        eng.upload(*init)
+        orc = O.Oracle(p, mode="mul", path_capacity=1 << 22)
+        orc.upload(*init)
+        npp = 0
+        for s in range(6):
+            st = eng.timestep(c["dt"])
+            rc, so = orc.timestep(c["dt"])
+            assert rc == 0
+            for k in ("n_pp", "n_wall", "n_paths", "n_fp_errors"):
+                assert st[k] == so[k], (mode, s, k, st, so)
+            npp += st["n_pp"]
+            assert_state_equal(eng.download(), orc.state(), ("tiled allpairs, pore", mode, s))
+        assert npp > 1000, npp
+        runs[mode] = eng.download()
+        eng.close()
+    for k in runs[1]:
+        assert np.array_equal(runs[1][k], runs[2][k]), k
+
+
 def test_candidate_overflow_is_reported_not_silent(Engine):
     from argon_monte_carlo_amd._lib import ArgonMCError
     n = 3000
