@@ -16,7 +16,7 @@ done
 for w in cube_allpairs_4096 cube_allpairs_1e5; do
     timeout -k 10 300 python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err" || echo "bench $w failed"
 done
-timeout -k 10 300 python bench.py --workload temp_1e6 --steps 20 --warmup 2 --no-python-mp-baseline > "$OUT/bench_temp_1e6.json" 2> "$OUT/bench_temp_1e6.err" || echo "bench temp failed"
+timeout -k 10 300 python bench.py --workload temp_1e6 --steps 200 --warmup 20 --no-python-mp-baseline > "$OUT/bench_temp_1e6.json" 2> "$OUT/bench_temp_1e6.err" || echo "bench temp failed"
 # the multi-GPU driver with one rank: same step through dist.ShardedSimulation, collective issued over RCCL
 timeout -k 10 300 python bench.py --force-sharded --workload cube_1e5 --steps 1000 --warmup 50 --no-cpu-baseline > "$OUT/bench_sharded1_cube_1e5.json" 2> "$OUT/bench_sharded1_cube_1e5.err" || echo "bench sharded failed"
 cd /tmp && export TMPDIR=/tmp
