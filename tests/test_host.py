@@ -178,6 +178,27 @@ def test_host_direction_helper_crosses_a_twister_refill():
         assert slow.np_rng.get_state()[2] == fast.np_rng.get_state()[2]
 
 
+def test_host_direction_helper_rejects_broken_states():
+    """amc_host_directions validates what it is handed (positions outside 0..624, missing buffers, a BLAS form without a
+    function) instead of reading past the key arrays."""
+    lib = _lib.load()
+    key = np.zeros(624, dtype=np.uint32)
+    nm = np.array([[0.0, 0.0, 1.0]])
+    out = np.zeros((1, 3))
+    u32p, dp = C.POINTER(C.c_uint32), C.POINTER(C.c_double)
+
+    def call(np_pos, py_pos, kind=0, fn=None, normals=nm, dirs=out, n=1):
+        a, b = C.c_int32(np_pos), C.c_int32(py_pos)
+        return lib.amc_host_directions(key.ctypes.data_as(u32p), C.byref(a), key.ctypes.data_as(u32p), C.byref(b),
+                                       normals.ctypes.data_as(dp) if normals is not None else None, None, n, 0.0871557, 3.141592653589793,
+                                       kind, fn, dirs.ctypes.data_as(dp) if dirs is not None else None)
+
+    assert call(625, 0) != 0 and call(0, -1) != 0
+    assert call(0, 0, kind=2, fn=None) != 0
+    assert call(0, 0, normals=None) != 0 and call(0, 0, dirs=None) != 0
+    assert call(0, 0, n=0) == 0
+
+
 def test_direction_sampler_falls_back_for_other_generators():
     """Anything that is not one of the two Mersenne Twisters keeps the per-hit loop (no state to borrow)."""
     import random
