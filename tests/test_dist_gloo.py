@@ -204,7 +204,7 @@ class _NoComm:
     def allreduce_sum_ints(self, v): return list(v)
 
 
-@pytest.mark.parametrize("n,world", [(240, 2), (251, 2), (251, 3)])       # equal and unequal shards
+@pytest.mark.parametrize("n,world", [(240, 2), (251, 2), (251, 3), (253, 8)])     # equal and unequal shards; 8 = the rank count of BASELINE configs[4]
 def test_ranks_equal_one_rank(n, world):
     steps = 6
     ref_sim, ref_tot = run_sim(n, 0, 1, steps, _NoComm())
