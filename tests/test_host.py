@@ -234,6 +234,30 @@ def test_gap_energies_in_worker_processes_equal_the_serial_ones(monkeypatch):
     assert en.gap_many(zs) == want and SurfaceEnergies._pool is None
 
 
+def test_direct_debye_integrand_equals_the_operator_form():
+    """SurfaceEnergies integrates x**3 / (exp(x) - 1) through libmp's functions directly (no mpf operator wrappers): the
+    gap energies and the two plate energies equal the ones the operator form gives — the reference's lambda, Temp:80 —
+    over the whole gap."""
+    from mpmath import exp
+    from argon_monte_carlo_amd.energised import SurfaceEnergies, _direct_debye_integrand
+    assert _direct_debye_integrand() is not None
+    _, c = PR.pore_params(n=100, energised=True)
+    fast = SurfaceEnergies(c)
+    assert fast._integrand.__name__ == "direct"
+    slow = SurfaceEnergies(c)
+    slow._integrand = lambda x: (x ** 3) / (exp(x) - 1)
+    z0 = c["open_air_height"] + c["hot_coating_height"]
+    rng = np.random.default_rng(5)
+    for z in np.concatenate([[z0, z0 + c["gap_height"]], z0 + c["gap_height"] * rng.random(25)]):
+        assert fast.gap(z) == slow.gap(z)
+    # the plate energies were integrated with the direct form too: compare with the operator form from scratch
+    from mpmath import quad
+    f = lambda x: (x ** 3) / (exp(x) - 1)                                    # noqa: E731
+    q = quad(f, [0, c["t_debye_graphene"] / c["t_cold"]])
+    want = 9 * c["t_cold"] * c["num_atoms_unitcell_graphene"] * c["boltzman"] * (c["t_cold"] / c["t_debye_graphene"]) ** 3 * q
+    assert float(want) == fast.cold
+
+
 def test_philox_reference_known_answers():
     """tests/philox_ref.py against the known-answer vectors of the Random123 distribution (kat_vectors, philox4x32 10)."""
     from tests.philox_ref import philox4x32_10
