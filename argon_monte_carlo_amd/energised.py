@@ -244,7 +244,8 @@ class SurfaceEnergies:
         from mpmath import exp, quad
         self._quad = quad
         self._integrand = lambda x: (x ** 3) / (exp(x) - 1)                  # Temp:80
-        fast = _direct_debye_integrand()
+        import os
+        fast = _direct_debye_integrand() if os.environ.get("AMC_DEBYE_DIRECT", "1") != "0" else None
         if fast is not None:
             self._integrand = fast
         c = consts
