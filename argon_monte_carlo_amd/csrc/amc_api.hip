@@ -216,7 +216,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
-    c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pin = nullptr;
+    c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pre_case = -1; c->T.pin = nullptr;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr; c->w_slab = nullptr; c->s_slab = nullptr;

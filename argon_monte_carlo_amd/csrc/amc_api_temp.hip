@@ -32,7 +32,7 @@ static int temp_ensure(amc_ctx *c)
     T.h_count = (int *)(h + o_count); T.h_idx = (int *)(h + o_idx); T.h_contact = (double *)(h + o_contact);
     T.h_normal = (double *)(h + o_normal); T.h_dir = (double *)(h + o_dir); T.h_Es = (double *)(h + o_Es);
     T.h_dpz = (double *)(h + o_dpz); T.h_dE = (double *)(h + o_dE);
-    T.last_case = -1; T.last_n = 0;
+    T.last_case = -1; T.last_n = 0; T.pre_case = -1;
     return AMC_OK;
 }
 
@@ -44,6 +44,7 @@ int amc_temp_begin(amc_ctx *c, double dt)
     if (rc) return rc;
     if ((rc = amc_flush(c))) return rc;
     c->keep_prior = true;       // the energised masks read prior_*_vals (Temp:708-750)
+    c->T.pre_case = -1;
     AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_DRIFT | AMC_ST_WALLS, 0));
     return AMC_OK;
 }
@@ -55,9 +56,14 @@ int amc_wall_hits(amc_ctx *c, int case_id, int32_t *idx, double *normal_xyz, dou
     int rc = temp_ensure(c);
     if (rc) return rc;
     amc_temp_ws &T = c->T;
-    AMC_HIP(c, amc_launch_temp_hits(c, case_id));
-    AMC_HIP(c, hipMemcpyAsync(T.h_count, T.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    AMC_HIP(c, hipStreamSynchronize(c->stream));        // the records are in host memory now (the kernel wrote them there)
+    if (T.pre_case == case_id) {
+        T.pre_case = -1;        // launched behind the previous case's apply kernel and already synchronised with it
+    } else {
+        T.pre_case = -1;
+        AMC_HIP(c, amc_launch_temp_hits(c, case_id));
+        AMC_HIP(c, hipMemcpyAsync(T.h_count, T.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        AMC_HIP(c, hipStreamSynchronize(c->stream));    // the records are in host memory now (the kernel wrote them there)
+    }
     const int cnt = *T.h_count;
     if (cnt > T.cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits exceed the record capacity %d", cnt, T.cap);
     if ((size_t)cnt > cap) return amc_fail(c, AMC_ERR_CAPACITY, "%d wall hits, caller buffer holds %zu", cnt, cap);
@@ -95,7 +101,18 @@ int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double 
         T.h_Es[k] = surface_energy[s];
     }
     AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n));
+    // The next case's mask is evaluated on the state this apply leaves (Temp:708-751: each mask after the previous handler)
+    // and needs nothing from the host: its hits kernel goes right behind, so that ONE synchronisation returns this case's
+    // results and the next case's hits (the hand-over of a step is synchronisation latency: 12 -> 7 of them).  The hit
+    // records are separate from what the apply kernel wrote back (dpz / dE) and from the host's copy of the permutation.
+    int pre = -1;
+    if (case_id < 9) {
+        AMC_HIP(c, amc_launch_temp_hits(c, case_id + 1));
+        AMC_HIP(c, hipMemcpyAsync(T.h_count, T.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        pre = case_id + 1;
+    }
     AMC_HIP(c, hipStreamSynchronize(c->stream));
+    T.pre_case = pre;
     for (size_t s = 0; s < n; s++) {
         if (dpz) dpz[s] = T.h_dpz[T.perm[s]];
         if (dE) dE[s] = T.h_dE[T.perm[s]];
@@ -266,6 +283,7 @@ int amc_temp_end(amc_ctx *c, amc_step_stats *out)
     if (!c || !c->uploaded) return AMC_ERR_STATE;
     AMC_HIP(c, hipSetDevice(c->device));
     if (c->P.geometry != AMC_GEOM_PORE_ENERGISED) return amc_fail(c, AMC_ERR_STATE, "amc_temp_end needs AMC_GEOM_PORE_ENERGISED");
+    c->T.pre_case = -1;
     // the bounds pass before the sweep sees every particle at its final pre-sweep position: it builds the detection
     // grid's lists as well (like the fused streaming pass of the specular geometries)
     const bool fuse = !c->allpairs && c->lo == 0 && c->hi == c->n;

@@ -125,6 +125,8 @@ struct amc_temp_ws {
     void *pin;
     int cap;
     int last_case, last_n;       // the pending amc_wall_hits
+    int pre_case;                // >= 0: the hits of this case are already in the records (launched behind the previous
+                                 // case's apply kernel: one synchronisation serves both)
     std::vector<int> perm;       // sorted position -> record slot of the pending hits
 };
 
