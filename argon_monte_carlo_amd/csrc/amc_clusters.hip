@@ -7,27 +7,33 @@
 // is emulated literally, restricted to its members, exactly as the ordered workgroup would do it (rs_emulate_pair /
 // rs_emulate_coop / rs_emulate_generic are shared); what is added here is only WHO does it and WHEN it is validated.
 //
-//   1. one lane per candidate k.  It reads the candidate record and the graph heads of its two particles (adjacency
-//      lists built by the detect kernel, amc_grid.hip).  Both lists hold only k  =>  isolated pair: the lane owns it.
-//      Otherwise the lane walks the component; it gives up as soon as it meets a candidate with a lower index (the
-//      lowest candidate's lane owns the component) or when the component exceeds CW_MAXM particles / CW_MAXC candidates
-//      (left to the ordered workgroup: nobody marks its candidates done).
-//   2. slots and history entries for everything the wave owns are reserved with ONE pair of counter increments
-//      (history: one entry pair per candidate; a cluster that hits more often than it has candidates takes the extra
-//      pairs from the counter and is flagged for the ordered workgroup, which redoes it — rare).
-//   3. isolated pairs are emulated by their lanes in registers; larger clusters one after the other by the whole wave
-//      (working set in LDS, members in ascending particle index).
-//   4. publish-then-probe: every new position is first pushed on the overlay list of its grid cell (write-through
-//      record, then a compare-and-swap on the list head — a reader never meets a half-linked entry), and only after
-//      ALL pushes of the wave have returned are the positions probed: against the pre-sweep positions of everything
-//      outside the cluster (the detection grid's lists) and against the other clusters' new positions (the overlay
-//      lists, read at agent scope).  Two clusters whose new positions conflict are both pushed before either probes
-//      or one probes after the other's push — at least one of them sees the other.  A hit becomes a merge edge (and a
-//      slot for a so far uninvolved particle) exactly like in the ordered workgroup's validation; the ordered workgroup
-//      then merges, re-emulates from the untouched pre-sweep state and validates again.
+//   1. one lane per candidate k.  It reads the candidate record (i, j, the candidates before it in the lists of i and j)
+//      and the candidate-indexed mark the detect kernel sets when a LATER candidate shares a particle with it
+//      (amc_push_candidate, amc_grid.hip).  Nobody before, nobody after  =>  isolated pair: the lane owns it and never
+//      touches the particle-indexed graph heads.  Otherwise the lane walks the component from the heads; it gives up as
+//      soon as it meets a candidate with a lower index (the lowest candidate's lane owns the component) or when the
+//      component exceeds CW_MAXM particles / CW_MAXC candidates (left to the ordered workgroup: nobody marks its
+//      candidates done).
+//   2. no allocation: candidate k brings slots 2k, 2k + 1 and the history / event pairs 4k, 4k + 2 (zeroed by the detect
+//      kernel when it pushed k); a cluster uses what its candidates brought.  Only a pulled-in particle's slot and a hit
+//      beyond 2 x candidates take entries from counters (behind 2 ncand / 4 ncand); such a cluster cannot be published
+//      here and is flagged for the ordered workgroup, which redoes it — rare.
+//   3. isolated pairs and 3-particle clusters are emulated by their lanes in registers; larger clusters one after the
+//      other by the whole wave (working set in LDS, members in ascending particle index).
+//   4. validation in two halves.  The new positions stay in LDS first and are probed against the pre-sweep positions of
+//      everything outside the cluster (the detection grid's lists).  A hit on a particle in no candidate pulls it in
+//      (compare-and-swap on slot_of) and the grown cluster is emulated again from the untouched pre-sweep state, up to
+//      CW_ITERS emulations; nothing of a superseded emulation was ever visible to another wave.  Then the FINAL
+//      emulation is published — write-through history records, each pushed on the overlay list of its grid cell by a
+//      compare-and-swap on the list head (a reader never meets a half-linked entry) — and only after ALL pushes of the
+//      wave have returned are the positions probed against the other clusters' new positions (the overlay lists, read
+//      at agent scope).  Two clusters whose new positions conflict are both pushed before either probes, or one probes
+//      after the other's push: at least one of them sees the other.  That hit becomes a merge edge for the ordered
+//      workgroup, which merges, re-emulates from the pre-sweep state and validates again.
 //
-// Bound: latency (a chain of ~8 dependent memory round trips per candidate), which is why the candidates are spread as
-// thinly as the launch allows: CW_BLOCKS one-wave workgroups, ceil(ncand / CW_BLOCKS) candidates per wave.
+// Bound: latency — ~6 dependent memory round trips of 0.5-0.6 us and ~2,000 instructions of one lane per candidate
+//  — which is why the candidates are spread as thinly as the launch allows: CW_BLOCKS one-wave
+// workgroups, ceil(ncand / CW_BLOCKS) candidates per wave.
 #include <stdlib.h>
 
 #define RS_WAVE_SYNC_LDS_ONLY 1     // one wave per cluster, working set in LDS (see rs_wave_sync)
