@@ -26,10 +26,11 @@
 // What is left for the ONE 512-thread workgroup of this file (phases separated by __syncthreads, counters in LDS; its
 // cost is latency, not throughput) is the entangled remainder: components too large for the wide kernel (claim,
 // label, emulate, validate as below), the later rounds after a validation found an outsider (merge along the new
-// edges, re-emulate only the touched clusters from the untouched pre-sweep state, validate again), and the commit of
-// a small sweep (a large one is committed by the wide k_commit).  When the wide kernel left nothing and found nothing
-// — the usual case — this kernel is the commit alone.  Without a detection grid (single cells, N <= 4096: MODE 2)
-// everything, brute-force validation included, happens here.
+// edges, re-emulate only the touched clusters from the untouched pre-sweep state, validate again).  When the wide
+// kernel left nothing and found nothing — 98 % of the sweeps at N = 1e5 — this kernel only hands the counters over.  The
+// commit is wide work again (amc_commit_dev.h): it rides along with the next streaming pass or runs as k_commit.
+// Without a detection grid (single cells, N <= 4096: MODE 2) everything, brute-force validation and commit included,
+// happens here.
 #include <stdlib.h>
 #include <algorithm>
 
