@@ -265,8 +265,7 @@ class SurfaceEnergies:
     # One mpmath.quad costs 0.7-1.5 ms of pure-Python multiprecision arithmetic and a step at N = 1e6 has about five gap
     # hits: half of the energised step's host time.  The integrals are independent and consume no random numbers, so the
     # hits of a case are spread over forked worker processes running this very method — same code, same mpmath, same
-    # bits.  (fork without exec: the children never touch the GPU and leave through os._exit; AMC_GAP_WORKERS=0 turns
-    # it off, =k sets the number of workers.)
+    # bits (_GapWorkers below; AMC_GAP_WORKERS=0 turns it off, =k sets the number of workers).
     _pool = None
     _pool_owner = None
 
@@ -286,32 +285,25 @@ class SurfaceEnergies:
 
     def _get_pool(self):
         cls = SurfaceEnergies
-        if cls._pool is not None and cls._pool_owner is self:
+        if cls._pool is not None and cls._pool_owner is self and cls._pool.alive():
             return cls._pool
-        if cls._pool is not None:
-            cls._pool.terminate()
-            cls._pool = None
+        cls._shutdown_pool()
         nw = self._workers_wanted()
         if nw < 2:
             return None
-        import atexit
-        import multiprocessing as mp
-        global _WORKER_ENERGIES
-        _WORKER_ENERGIES = self                      # inherited by the forked workers
         try:
-            cls._pool = mp.get_context("fork").Pool(nw)
-        except (OSError, ValueError):
+            cls._pool = _GapWorkers(self, nw)
+        except OSError:
             cls._pool = None
             return None
         cls._pool_owner = self
-        atexit.register(cls._shutdown_pool)
         return cls._pool
 
     @classmethod
     def _shutdown_pool(cls):
         if cls._pool is not None:
             try:
-                cls._pool.terminate()
+                cls._pool.close()
             except Exception:
                 pass
             cls._pool = None
@@ -324,9 +316,9 @@ class SurfaceEnergies:
             pool = self._get_pool()
             if pool is not None:
                 try:
-                    return pool.map(_gap_in_worker, zs, chunksize=1)
+                    return pool.map(zs)
                 except Exception:
-                    SurfaceEnergies._shutdown_pool()            # (a dead worker: fall back to this process for good)
+                    SurfaceEnergies._shutdown_pool()            # (a dead worker: this process does it, now and from now on)
                     import os
                     os.environ["AMC_GAP_WORKERS"] = "0"
         return [self.gap(z) for z in zs]
@@ -339,11 +331,126 @@ class SurfaceEnergies:
         return float(9 * t_gap * self.n_alumina * self.boltzman * (t_gap / self.t_debye_alumina) ** 3 * q)   # Temp:152
 
 
-_WORKER_ENERGIES = None
+class _GapWorkers:
+    """A few forked copies of this process that evaluate SurfaceEnergies.gap on request.
 
+    fork without exec: a child keeps the parent's memory (mpmath, the constants, the quadrature nodes already cached) and
+    nothing else — right after the fork it closes every inherited descriptor but its own two pipe ends (the parent's
+    stdout / stderr pipes, sockets of a process group, the GPU's device files: a child that held them would keep a pipe
+    reader waiting after the parent is gone, and count as a process with the GPU open), points 0-2 at /dev/null, asks
+    the kernel to kill it when the parent dies, never touches the GPU runtime and leaves through os._exit.  A request is
+    the 8 bytes of a double; the answer likewise."""
 
-def _gap_in_worker(z):
-    return _WORKER_ENERGIES.gap(z)
+    def __init__(self, energies, n):
+        import os
+        import struct
+        self._struct = struct.Struct("<d")
+        self.workers = []
+        parent = os.getpid()
+        try:
+            for _ in range(n):
+                req_r, req_w = os.pipe()
+                ans_r, ans_w = os.pipe()
+                pid = os.fork()
+                if pid == 0:
+                    self._child(energies, req_r, ans_w, parent)          # never returns
+                os.close(req_r)
+                os.close(ans_w)
+                self.workers.append((pid, req_w, ans_r))
+        except OSError:
+            self.close()
+            raise
+        import atexit
+        atexit.register(self.close)
+
+    def _child(self, energies, req_r, ans_w, parent):
+        import os
+        code = 0
+        try:
+            try:
+                import ctypes
+                import signal
+                ctypes.CDLL(None).prctl(1, int(signal.SIGKILL), 0, 0, 0)     # PR_SET_PDEATHSIG
+                if os.getppid() != parent:
+                    os._exit(0)
+            except Exception:
+                pass
+            keep = {req_r, ans_w}
+            try:
+                fds = [int(f) for f in os.listdir("/proc/self/fd")]
+            except OSError:
+                fds = list(range(3, 1024))
+            null = os.open(os.devnull, os.O_RDWR)
+            keep.add(null)
+            for fd in fds:
+                if fd > 2 and fd not in keep:
+                    try:
+                        os.close(fd)
+                    except OSError:
+                        pass
+            for fd in (0, 1, 2):
+                os.dup2(null, fd)
+            st = self._struct
+            while True:
+                buf = b""
+                while len(buf) < 8:
+                    chunk = os.read(req_r, 8 - len(buf))
+                    if not chunk:
+                        os._exit(0)                                         # the parent closed the pipe
+                    buf += chunk
+                os.write(ans_w, st.pack(energies.gap(st.unpack(buf)[0])))
+        except BaseException:
+            code = 1
+        finally:
+            os._exit(code)
+
+    def alive(self):
+        import os
+        for pid, _, _ in self.workers:
+            try:
+                if os.waitpid(pid, os.WNOHANG)[0] != 0:
+                    return False
+            except ChildProcessError:
+                return False
+        return bool(self.workers)
+
+    def map(self, zs):
+        import os
+        st, nw = self._struct, len(self.workers)
+        out = [0.0] * len(zs)
+        for base in range(0, len(zs), nw):                       # one request in flight per worker
+            batch = zs[base:base + nw]
+            for k, z in enumerate(batch):
+                os.write(self.workers[k][1], st.pack(z))
+            for k in range(len(batch)):
+                buf = b""
+                while len(buf) < 8:
+                    chunk = os.read(self.workers[k][2], 8 - len(buf))
+                    if not chunk:
+                        raise RuntimeError("a gap-energy worker went away")
+                    buf += chunk
+                out[base + k] = st.unpack(buf)[0]
+        return out
+
+    def close(self):
+        import os
+        import signal
+        workers, self.workers = self.workers, []
+        for pid, req_w, ans_r in workers:
+            for fd in (req_w, ans_r):
+                try:
+                    os.close(fd)
+                except OSError:
+                    pass
+        for pid, _, _ in workers:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except OSError:
+                pass
+            try:
+                os.waitpid(pid, 0)
+            except (ChildProcessError, OSError):
+                pass
 
 
 def sequential_sum(values):

@@ -226,10 +226,18 @@ def test_gap_energies_in_worker_processes_equal_the_serial_ones(monkeypatch):
     monkeypatch.setenv("AMC_GAP_WORKERS", "3")
     try:
         assert en.gap_many(zs) == want
-        assert SurfaceEnergies._pool is not None
+        assert SurfaceEnergies._pool is not None and SurfaceEnergies._pool.alive()
+        pids = [w[0] for w in SurfaceEnergies._pool.workers]
+        assert len(pids) == 3
+        # a worker holds nothing of the parent's but its two pipe ends (no inherited stdout pipe, socket or device file)
+        for pid in pids:
+            links = [os.readlink(f"/proc/{pid}/fd/{f}") for f in os.listdir(f"/proc/{pid}/fd")]
+            assert sum(l.startswith("pipe:") for l in links) == 2 and all(l.startswith("pipe:") or l == "/dev/null" for l in links), links
         assert en.gap_many(zs[:1]) == want[:1] and en.gap_many([]) == []
     finally:
         SurfaceEnergies._shutdown_pool()
+    for pid in pids:
+        assert not os.path.exists(f"/proc/{pid}") or open(f"/proc/{pid}/stat").read().split()[2] == "Z"
     monkeypatch.setenv("AMC_GAP_WORKERS", "0")
     assert en.gap_many(zs) == want and SurfaceEnergies._pool is None
 
