@@ -85,7 +85,8 @@ struct cw_lds {
     int cnd[64][CW_MAXC];       // its candidates: candidate c brings slots 2c, 2c + 1 and the history pairs 4c, 4c + 2
     int pull[64][CW_PULLS], psl[64][CW_PULLS];     // particles (and their new slots) the last validation pulled in
     int nm[64], nc[64], lab[64], npull[64];         // members, candidates, cluster label (= first slot), pulls
-    int it0[64];                // first work item of the owner's current emulation (its items are contiguous, in hit order)
+    int it0[64], itl[64];       // first / latest pair of work items of the owner's current emulation
+    int pnext[CW_ITEMS / 2];    // pair (item index / 2) -> the same owner's next pair (item index), -1 = last
     int used[64];               // history pairs the running emulation has taken
     int redo[64];               // the cluster must be emulated (again) by the wave
     int gen[64];                // emulations done
@@ -153,18 +154,27 @@ AMC_DEV void cw_probe_overlay(const rs_args &A, rs_shared *wc, cw_lds &L, const 
     // the published entries of my own cluster — the pairs its candidates brought along, in the order its final emulation
     // took them — are stepped over through the `next` values their pushes returned (LDS), without a load
     auto skip_own = [&](int h2) {
-        while (h2 >= 0 && h2 < h_off) {
+        for (int steps = 0; h2 >= 0 && h2 < h_off && steps < CW_ITEMS; steps++) {
             const int c = h2 >> 2, second = (h2 >> 1) & 1, ncs = L.nc[own];
             int t = -1;
             for (int q = 0; q < ncs; q++)
-                if (L.cnd[own][q] == c) { t = L.it0[own] + 2 * (q + second * ncs) + (h2 & 1); break; }
-            if (t < 0) break;
+                if (L.cnd[own][q] == c) {
+                    // hit number q + second * ncs of my final emulation: its pair of items is that many links down my chain
+                    // (NOT that many pairs behind the first: the lanes of a wave append in lockstep, their pairs interleave)
+                    t = L.it0[own];
+                    for (int u = q + second * ncs; u > 0 && t >= 0; u--) t = L.pnext[t >> 1];
+                    if (t >= 0) t += h2 & 1;
+                    break;
+                }
+            if (t < 0 || t >= CW_ITEMS || L.item[t].h != h2) break;     // (not an item of mine after all: handled like anybody's entry)
             h2 = L.next[t];
         }
         return h2;
     };
     int h2 = skip_own(__hip_atomic_load(&W.ov_head[cell], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    int guard = 0;
     while (h2 >= 0) {
+        if (++guard > W.max_hist) { wc->ovf = 1; break; }      // (a list cannot be longer than there are entries: reported, not spun on)
         const double4 o = cw_load_hist(W, h2);
         const int nx = __hip_atomic_load(&W.ov_next[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         h2 = skip_own(nx);
@@ -203,7 +213,7 @@ AMC_DEV int cw_prepare(const amc_resolve_ws &W, rs_shared *wc, cw_lds &L, int ow
     }
     L.nm[own] = m; L.npull[own] = 0;
     L.used[own] = 0;
-    L.it0[own] = -1;
+    L.it0[own] = -1; L.itl[own] = -1;
     return m;
 }
 
@@ -213,7 +223,7 @@ AMC_DEV void cw_wide_hooks(rs_wide &wd, cw_lds &L, int own, int h_off)
     wd.cnd = L.cnd[own]; wd.ncnd = L.nc[own];
     wd.used = &L.used[own]; wd.h_off = h_off;
     wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own]; wd.unval = &L.unv[own];
+    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own]; wd.it_last = &L.itl[own]; wd.pnext = L.pnext; wd.unval = &L.unv[own];
 }
 
 // slots of the cluster's candidates (first emulation only)
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         const bool take = iso || owner;
         L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = 2 * k; L.npull[lane] = 0;
         for (int m = 0; m < nm; m++) L.msl[lane][m] = 2 * cnd[m >> 1] + (m & 1);
-        L.it0[lane] = -1;
+        L.it0[lane] = -1; L.itl[lane] = -1;
         L.redo[lane] = take ? 1 : 0;
         L.gen[lane] = 0;
         if (timed__) cat__ = !take ? 3 : (nm == 2 ? 0 : (nm == 3 ? 1 : 2));
