@@ -220,6 +220,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr; c->w_slab = nullptr; c->s_slab = nullptr;
+    c->cw_blocks_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;
     c->mg_count_pp = true;
     c->lazy_pending = false; c->commit_pending = false; c->commit_defer = false;
     c->h_host_ncand = nullptr; c->d_host_ncand = nullptr;

@@ -533,7 +533,9 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
 
 int amc_clusters_wide_blocks(amc_ctx *c)
 {
-    static const int nb_env = getenv("AMC_CW_BLOCKS") ? atoi(getenv("AMC_CW_BLOCKS")) : 0;     // (experiments)
+    // AMC_CW_BLOCKS (read when the context is created): fewer waves = more clusters per wave — tests use it to put many
+    // clusters, multi-hit ones among them, into the same wave at sizes the oracle handles in seconds
+    const int nb_env = c->cw_blocks_env;
     if (nb_env > 0) return (nb_env + CW_WPB - 1) / CW_WPB * CW_WPB;
     return CW_BLOCKS;
 }

@@ -172,6 +172,7 @@ struct amc_ctx {
     amc_counter_bank *d_banks;   // banked per-event counters, folded into the copy read_counters() returns
     amc_dev_counters h_prev;  // snapshot used to report per-step deltas
     long long *d_dbg;         // resolve phase timers (diagnostic, enabled by AMC_DEBUG_RESOLVE=1)
+    int cw_blocks_env;        // AMC_CW_BLOCKS at creation (0 = default number of wide-kernel waves)
     // profiling
     bool profiling;
     double k_ms[AMC_K_COUNT];

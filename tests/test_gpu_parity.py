@@ -462,9 +462,14 @@ def test_tiny_and_empty_systems(Engine, O, kind, n):
         eng.close()
 
 
-def test_dense_cluster_chains_match_oracle(Engine, O):
+@pytest.mark.parametrize("wide_waves", [0, 4, 16])
+def test_dense_cluster_chains_match_oracle(Engine, O, monkeypatch, wide_waves):
     """A dense blob (volume fraction ~20 %): long collision chains and many validation rounds; both detectors agree
-    with the oracle bit for bit."""
+    with the oracle bit for bit.  With 4 or 16 waves in the wide cluster kernel instead of 512 (AMC_CW_BLOCKS, read at
+    context creation) up to 64 clusters share a wave: multi-hit clusters emulated in lockstep, their work items
+    interleaved — the configuration a sweep with tens of thousands of candidates runs in."""
+    if wide_waves:
+        monkeypatch.setenv("AMC_CW_BLOCKS", str(wide_waves))
     n = 400
     rng = np.random.default_rng(99)
     for mode in (1, 2):
@@ -490,12 +495,15 @@ def test_dense_cluster_chains_match_oracle(Engine, O):
         eng.close()
 
 
-@pytest.mark.parametrize("kind,n,sigma_mult,steps", [("cube", 30_000, 16.0, 25), ("pore", 60_000, 30.0, 25)])
-def test_high_collision_rate_stresses_the_wide_cluster_kernel(Engine, O, kind, n, sigma_mult, steps):
+@pytest.mark.parametrize("kind,n,sigma_mult,steps,wide_waves", [("cube", 30_000, 16.0, 25, 0), ("pore", 60_000, 30.0, 25, 0),
+                                                              ("cube", 30_000, 16.0, 10, 8), ("pore", 60_000, 30.0, 10, 8)])
+def test_high_collision_rate_stresses_the_wide_cluster_kernel(Engine, O, monkeypatch, kind, n, sigma_mult, steps, wide_waves):
     """A cross-section 16-30 times the reference's: several per cent of the particles collide in every step, so that
     three- to ten-particle clusters, pulled-in particles, re-emulations and cluster-cluster conflicts (the concurrent
     publish-then-probe protocol of k_clusters_wide) all happen in every sweep.  State and counters equal the oracle's bit
     for bit at every step."""
+    if wide_waves:              # (AMC_CW_BLOCKS: 8 waves of 64 clusters each, several passes — see the dense-blob test)
+        monkeypatch.setenv("AMC_CW_BLOCKS", str(wide_waves))
     sigma = 3.6e-19 * sigma_mult
     if kind == "cube":
         p, c = PR.cube_params_for_n(n, sigma=sigma)
@@ -519,7 +527,7 @@ def test_high_collision_rate_stresses_the_wide_cluster_kernel(Engine, O, kind, n
         npp += st["n_pp"]
         rounds += st["n_rounds"]
         assert_state_equal(eng.download(), orc.state(), ("stress", kind, s))
-    assert npp > (0.01 * n * steps / 2 if kind == "cube" else 1500), npp      # really a high collision rate (the pore's dt shrinks with the cross-section)
+    assert npp > (0.01 * n * steps / 2 if kind == "cube" else 60 * steps), npp      # really a high collision rate (the pore's dt shrinks with the cross-section)
     eng.close()
 
 
