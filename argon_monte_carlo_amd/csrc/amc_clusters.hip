@@ -85,8 +85,7 @@ struct cw_lds {
     int cnd[64][CW_MAXC];       // its candidates: candidate c brings slots 2c, 2c + 1 and the history pairs 4c, 4c + 2
     int pull[64][CW_PULLS], psl[64][CW_PULLS];     // particles (and their new slots) the last validation pulled in
     int nm[64], nc[64], lab[64], npull[64];         // members, candidates, cluster label (= first slot), pulls
-    int it0[64], itl[64];       // first / latest pair of work items of the owner's current emulation
-    int pnext[CW_ITEMS / 2];    // pair (item index / 2) -> the same owner's next pair (item index), -1 = last
+    int it0[64];                // first pair of work items of the owner's current emulation
     int used[64];               // history pairs the running emulation has taken
     int redo[64];               // the cluster must be emulated (again) by the wave
     int gen[64];                // emulations done
@@ -158,15 +157,12 @@ AMC_DEV void cw_probe_overlay(const rs_args &A, rs_shared *wc, cw_lds &L, const 
             const int c = h2 >> 2, second = (h2 >> 1) & 1, ncs = L.nc[own];
             int t = -1;
             for (int q = 0; q < ncs; q++)
-                if (L.cnd[own][q] == c) {
-                    // hit number q + second * ncs of my final emulation: its pair of items is that many links down my chain
-                    // (NOT that many pairs behind the first: the lanes of a wave append in lockstep, their pairs interleave)
-                    t = L.it0[own];
-                    for (int u = q + second * ncs; u > 0 && t >= 0; u--) t = L.pnext[t >> 1];
-                    if (t >= 0) t += h2 & 1;
-                    break;
-                }
-            if (t < 0 || t >= CW_ITEMS || L.item[t].h != h2) break;     // (not an item of mine after all: handled like anybody's entry)
+                if (L.cnd[own][q] == c) { t = L.it0[own] + 2 * (q + second * ncs) + (h2 & 1); break; }
+            // Hit number q + second * ncs of my final emulation sits that many pairs behind my first one ONLY if no other
+            // lane appended in between — the lanes of a wave emulate in lockstep and share the list, so the pairs of two
+            // multi-hit clusters interleave.  The item says whose entry it holds: anything else is left to the walk below,
+            // which treats it like anybody's entry (a load more, the same result).
+            if (t < 0 || t >= CW_ITEMS || L.item[t].h != h2) break;
             h2 = L.next[t];
         }
         return h2;
@@ -213,7 +209,7 @@ AMC_DEV int cw_prepare(const amc_resolve_ws &W, rs_shared *wc, cw_lds &L, int ow
     }
     L.nm[own] = m; L.npull[own] = 0;
     L.used[own] = 0;
-    L.it0[own] = -1; L.itl[own] = -1;
+    L.it0[own] = -1;
     return m;
 }
 
@@ -223,7 +219,7 @@ AMC_DEV void cw_wide_hooks(rs_wide &wd, cw_lds &L, int own, int h_off)
     wd.cnd = L.cnd[own]; wd.ncnd = L.nc[own];
     wd.used = &L.used[own]; wd.h_off = h_off;
     wd.items = L.item; wd.nitems = &L.nitems; wd.cap = CW_ITEMS;
-    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own]; wd.it_last = &L.itl[own]; wd.pnext = L.pnext; wd.unval = &L.unv[own];
+    wd.own = own; wd.gen = g + 1; wd.it0 = &L.it0[own]; wd.unval = &L.unv[own];
 }
 
 // slots of the cluster's candidates (first emulation only)
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         const bool take = iso || owner;
         L.nm[lane] = nm; L.nc[lane] = nc; L.lab[lane] = 2 * k; L.npull[lane] = 0;
         for (int m = 0; m < nm; m++) L.msl[lane][m] = 2 * cnd[m >> 1] + (m & 1);
-        L.it0[lane] = -1; L.itl[lane] = -1;
+        L.it0[lane] = -1;
         L.redo[lane] = take ? 1 : 0;
         L.gen[lane] = 0;
         if (timed__) cat__ = !take ? 3 : (nm == 2 ? 0 : (nm == 3 ? 1 : 2));

@@ -154,10 +154,6 @@ struct rs_wide {
     int own;
     int gen;                  // round tag of this emulation (the wide kernel re-emulates a cluster that pulled a particle in)
     int *it0;                 // where the owner's first pair of work items of this emulation went (-1: none yet)
-    int *it_last;             // ... and its latest pair
-    int *pnext;               // [cap / 2] pair of items (index / 2) -> the owner's next pair (item index), -1 = last: the lanes of
-                              // a wave emulate their clusters in lockstep and append to ONE list, so an owner's pairs interleave
-                              // with the other owners'
     int *unval;               // set when a hit got entries the wave cannot publish: the ordered workgroup redoes the cluster
 };
 
@@ -222,10 +218,8 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
             // pair of a failed hit keeps its place in the list (pad = 1: neither published nor probed)
             const int it = atomicAdd(wd->nitems, 2);
             if (it + 2 <= wd->cap) {
-                if (*wd->it0 < 0) *wd->it0 = it;             // the owner's pairs, chained in the order of its reserved entries
-                else wd->pnext[*wd->it_last >> 1] = it;
-                *wd->it_last = it;
-                wd->pnext[it >> 1] = -1;
+                if (*wd->it0 < 0) *wd->it0 = it;             // (the owner's later pairs follow it directly only if no other lane of
+                                                            // the wave appended in between: cw_probe_overlay checks before it relies on that)
                 cw_item a, b;
                 a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd->own; a.p = pj; a.pad = fail | (wd->gen << 1);
                 b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd->own; b.p = pi; b.pad = fail | (wd->gen << 1);
