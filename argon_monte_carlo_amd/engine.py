@@ -223,9 +223,10 @@ class EnergisedEngine(Engine):
 
     def wall_hits(self, case):
         cap = max(4096, self.n // 8 + 1024)
-        idx = np.empty(cap, dtype=np.int32)
-        normal = np.empty((cap, 3))
-        cz = np.empty(cap)
+        buf = getattr(self, "_wall_hit_buffers", None)
+        if buf is None or len(buf[0]) != cap:       # (kept across calls: seven allocations of megabytes per step otherwise)
+            buf = self._wall_hit_buffers = (np.empty(cap, dtype=np.int32), np.empty((cap, 3)), np.empty(cap))
+        idx, normal, cz = buf
         n = C.c_size_t(0)
         self._ck(self.lib.amc_wall_hits(self._ctx, int(case), idx.ctypes.data_as(C.POINTER(C.c_int32)), _d(normal), _d(cz),
                                         cap, C.byref(n)))
