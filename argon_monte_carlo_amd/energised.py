@@ -495,25 +495,26 @@ def drive_energised_cases(hooks, sampler, energies):
                 for k in range(n):
                     if ok[k]:                               # (else: the reference's try-block fails before any RNG draw)
                         dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
-            good = [k for k in range(n) if ok[k]]
+            good = np.flatnonzero(np.asarray(ok))
             Es = np.zeros(n)
             if case == GAP_CASE:
                 if hasattr(energies, "gap_many"):
-                    Es[good] = energies.gap_many([contact_z[k] for k in good])
+                    Es[good] = energies.gap_many(np.asarray(contact_z)[good].tolist())
                 else:
                     for k in good:
                         Es[k] = energies.gap(contact_z[k])
             else:
                 Es[good] = energies.cold if case in COLD_CASES else energies.hot
             dpz, dE = hooks.wall_apply(case, dirs, Es)
-            m_case = sequential_sum(dpz[k] for k in good)
+            # (left-to-right sums over plain Python floats: the same additions in the same order as the reference's loop)
+            m_case = sequential_sum(np.asarray(dpz, dtype=np.float64)[good].tolist())
             mom = mom + m_case
             had_m = had_m or len(good) > 0
             if case in COLD_CASES:
-                cold = cold + sequential_sum(dE[k] for k in good)
+                cold = cold + sequential_sum(np.asarray(dE, dtype=np.float64)[good].tolist())
                 had_c = had_c or len(good) > 0
             elif case in HOT_CASES:
-                hot = hot + sequential_sum(dE[k] for k in good)
+                hot = hot + sequential_sum(np.asarray(dE, dtype=np.float64)[good].tolist())
                 had_h = had_h or len(good) > 0
     return mom, cold, hot, had_m, had_c, had_h
 
