@@ -242,6 +242,26 @@ def test_gap_energies_in_worker_processes_equal_the_serial_ones(monkeypatch):
     assert en.gap_many(zs) == want and SurfaceEnergies._pool is None
 
 
+def test_gap_energies_survive_a_dead_worker(monkeypatch):
+    """A worker that went away (killed, out of memory) must not cost the step: gap_many notices, does the integrals in
+    this process and stops using workers."""
+    import signal
+    from argon_monte_carlo_amd.energised import SurfaceEnergies
+    _, c = PR.pore_params(n=100, energised=True)
+    en = SurfaceEnergies(c)
+    z0 = c["open_air_height"] + c["hot_coating_height"]
+    zs = [z0 + f * c["gap_height"] for f in (0.1, 0.4, 0.9)]
+    want = [en.gap(z) for z in zs]
+    monkeypatch.setenv("AMC_GAP_WORKERS", "2")
+    try:
+        assert en.gap_many(zs) == want
+        os.kill(SurfaceEnergies._pool.workers[0][0], signal.SIGKILL)
+        assert en.gap_many(zs) == want                  # (either path: restarted workers or this process)
+        assert en.gap_many(zs) == want
+    finally:
+        SurfaceEnergies._shutdown_pool()
+
+
 def test_direct_debye_integrand_equals_the_operator_form():
     """SurfaceEnergies integrates x**3 / (exp(x) - 1) through libmp's functions directly (no mpf operator wrappers): the
     gap energies and the two plate energies equal the ones the operator form gives — the reference's lambda, Temp:80 —
