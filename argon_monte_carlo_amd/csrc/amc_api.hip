@@ -37,12 +37,14 @@ void amc_prof_begin(amc_ctx *c, int kclass)
         c->ev_pool.push_back({a, b});
     }
     c->ev_pending.push_back({kclass, (int)c->ev_used});
-    hipEventRecord(c->ev_pool[c->ev_used].first, c->stream);
+    // the launch inside the bracket takes the two events with it (AMC_LAUNCH)
+    c->prof_ev0 = c->ev_pool[c->ev_used].first;
+    c->prof_ev1 = c->ev_pool[c->ev_used].second;
 }
 void amc_prof_end(amc_ctx *c)
 {
     if (!c->profiling) return;
-    hipEventRecord(c->ev_pool[c->ev_used].second, c->stream);
+    c->prof_ev0 = c->prof_ev1 = nullptr;
     c->ev_used++;
     if (c->ev_used >= 4096) amc_prof_collect(c);
 }
@@ -50,6 +52,7 @@ void amc_prof_cancel(amc_ctx *c)        // drop the open bracket (nothing was la
 {
     if (!c->profiling || c->ev_pending.empty()) return;
     c->ev_pending.pop_back();
+    c->prof_ev0 = c->prof_ev1 = nullptr;
 }
 void amc_prof_collect(amc_ctx *c)
 {
@@ -212,6 +215,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->keep_prior = (p->reserved0 & 1) != 0;
     c->profiling = false;
     c->ev_used = 0;
+    c->prof_ev0 = c->prof_ev1 = nullptr;
     memset(c->k_ms, 0, sizeof c->k_ms);
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);

@@ -542,11 +542,11 @@ hipError_t amc_launch_clusters_wide(amc_ctx *c, const rs_args &A)
     const dim3 grid((nb + CW_WPB - 1) / CW_WPB), block(64 * CW_WPB);
     const bool cube = c->P.geometry == AMC_GEOM_CUBE;
     if (A.dbg) {        // AMC_DEBUG_RESOLVE=1: the instantiation with the phase timers
-        if (cube) hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE, true>), grid, block, 0, c->stream, A);
-        else hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE, true>), grid, block, 0, c->stream, A);
+        if (cube) AMC_LAUNCH(c, (k_clusters_wide<AMC_GEOM_CUBE, true>), grid, block, A);
+        else AMC_LAUNCH(c, (k_clusters_wide<AMC_GEOM_PORE, true>), grid, block, A);
     } else {
-        if (cube) hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_CUBE, false>), grid, block, 0, c->stream, A);
-        else hipLaunchKernelGGL((k_clusters_wide<AMC_GEOM_PORE, false>), grid, block, 0, c->stream, A);
+        if (cube) AMC_LAUNCH(c, (k_clusters_wide<AMC_GEOM_CUBE, false>), grid, block, A);
+        else AMC_LAUNCH(c, (k_clusters_wide<AMC_GEOM_PORE, false>), grid, block, A);
     }
     return hipGetLastError();
 }

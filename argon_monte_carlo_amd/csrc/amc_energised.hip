@@ -147,7 +147,7 @@ hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id)
     const long long cnt = c->hi - c->lo;
     hipError_t e = hipMemsetAsync(c->T.count, 0, sizeof(int), c->stream);
     if (e != hipSuccess || cnt <= 0) return e;
-    hipLaunchKernelGGL(k_temp_hits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, case_id,
+    AMC_LAUNCH(c, k_temp_hits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), c->S, c->P, case_id,
                        c->lo, c->hi, make_records(c), c->d_cnt);
     return hipGetLastError();
 }
@@ -155,7 +155,7 @@ hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id)
 hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_temp_apply, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->S, c->P, c->out, case_id, n,
+    AMC_LAUNCH(c, k_temp_apply, dim3((n + 255) / 256), dim3(256), c->S, c->P, c->out, case_id, n,
                        make_records(c), c->T.dir, c->T.Es, c->T.dpz, c->T.dE);
     return hipGetLastError();
 }
@@ -299,7 +299,7 @@ hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
         temp_dev_segments G;
         G.idx = D.idx; G.count = D.count; G.t = D.t; G.contact = D.contact; G.normal = D.normal; G.dir = D.dir;
         G.Es = D.Es; G.dpz = D.dpz; G.dE = D.dE; G.ok = D.ok; G.cap = D.cap;
-        hipLaunchKernelGGL(k_temp_all, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, c->out, *cfg,
+        AMC_LAUNCH(c, k_temp_all, dim3((unsigned)((cnt + 255) / 256)), dim3(256), c->S, c->P, c->out, *cfg,
                            (unsigned int)c->out.step, c->lo, c->hi, G, c->d_cnt);
         return hipGetLastError();
     }
@@ -310,11 +310,11 @@ hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
         temp_records R;
         R.idx = D.idx + o; R.t = D.t + o; R.contact = D.contact + 3 * o; R.normal = D.normal + 3 * o; R.ok = D.ok + o;
         R.count = D.count + s; R.cap = D.cap;
-        hipLaunchKernelGGL(k_temp_hits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, case_id,
+        AMC_LAUNCH(c, k_temp_hits, dim3((unsigned)((cnt + 255) / 256)), dim3(256), c->S, c->P, case_id,
                            c->lo, c->hi, R, c->d_cnt);
-        hipLaunchKernelGGL(k_temp_sample, dim3(rec_blocks), dim3(256), 0, c->stream, c->P, *cfg, case_id,
+        AMC_LAUNCH(c, k_temp_sample, dim3(rec_blocks), dim3(256), c->P, *cfg, case_id,
                            (unsigned int)c->out.step, R, D.dir + 3 * o, D.Es + o);
-        hipLaunchKernelGGL(k_temp_apply, dim3(rec_blocks), dim3(256), 0, c->stream, c->S, c->P, c->out, case_id, -1, R,
+        AMC_LAUNCH(c, k_temp_apply, dim3(rec_blocks), dim3(256), c->S, c->P, c->out, case_id, -1, R,
                            D.dir + 3 * o, D.Es + o, D.dpz + o, D.dE + o);
     }
     return hipGetLastError();

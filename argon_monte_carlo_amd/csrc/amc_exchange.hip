@@ -130,11 +130,11 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
             if (e != hipSuccess) return e;
         }
         c->kin_counts_clear = false;
-        hipLaunchKernelGGL(k_kin_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, S, (long long)c->lo,
+        AMC_LAUNCH(c, k_kin_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), S, (long long)c->lo,
                            (long long)c->hi, m, capb, c->kin_send, c->G, c->B, c->d_cnt);
     } else {
         const long long per = m > c->kin_cap ? m : c->kin_cap;
-        hipLaunchKernelGGL(k_kin_unpack, dim3((unsigned)(((long long)world * per + 255) / 256)), dim3(256), 0, c->stream, S,
+        AMC_LAUNCH(c, k_kin_unpack, dim3((unsigned)(((long long)world * per + 255) / 256)), dim3(256), S,
                            (long long)c->n, world, rank, m, capb, c->kin_recv, c->G, c->B, c->d_cnt, c->W.slot_of, c->kin_send);
         c->kin_counts_clear = true;
     }

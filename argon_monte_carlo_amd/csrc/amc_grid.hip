@@ -195,7 +195,7 @@ hipError_t amc_launch_bin(amc_ctx *c)
     const long long n = c->n;
     c->B.epoch++;
     amc_prof_begin(c, AMC_K_BIN_COUNT);
-    hipLaunchKernelGGL(k_bin_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->S.x, c->S.y, c->S.z, n,
+    AMC_LAUNCH(c, k_bin_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), c->S.x, c->S.y, c->S.z, n,
                        c->G, c->B, c->d_cnt);
     amc_prof_end(c);
     return hipGetLastError();
@@ -288,17 +288,17 @@ hipError_t amc_launch_detect(amc_ctx *c)
             // coordinates relative to the grid origin; threshold raised by the cancellation bound of the expanded form
             const double ex = c->G.gx * c->G.h, ey = c->G.gy * c->G.h, ez = c->G.gz * c->G.h;
             const double thr = cr2i + 64.0 * 1.1102230246251565e-16 * (ex * ex + ey * ey + ez * ez);
-            hipLaunchKernelGGL(k_detect_allpairs_tiled, dim3((unsigned)nblocks), dim3(AP2_THREADS), 0, c->stream, c->S.x, c->S.y,
+            AMC_LAUNCH(c, k_detect_allpairs_tiled, dim3((unsigned)nblocks), dim3(AP2_THREADS), c->S.x, c->S.y,
                                c->S.z, (int)n, ntiles, thr, c->G.x0, c->G.y0, c->G.z0, c->W.max_cand, c->d_cnt, D);
         } else {
             const int ntiles = (int)((n + AP_T - 1) / AP_T);
             const long long nblocks = (long long)ntiles * (ntiles + 1) / 2;
             if (nblocks > 0)
-                hipLaunchKernelGGL(k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), 0, c->stream, c->S.x, c->S.y,
+                AMC_LAUNCH(c, k_detect_allpairs, dim3((unsigned)nblocks), dim3(AP_T), c->S.x, c->S.y,
                                    c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
         }
     } else {
-        hipLaunchKernelGGL(k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->G, c->B, n, cr2i,
+        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), c->G, c->B, n, cr2i,
                            c->G.cr_probe, c->W.max_cand, c->d_cnt, D);
     }
     amc_prof_end(c);

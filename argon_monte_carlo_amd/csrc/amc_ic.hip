@@ -63,7 +63,7 @@ extern "C" int amc_init_synthetic(amc_ctx *c, const amc_ic_config *cfg)
     AMC_HIP(c, hipSetDevice(c->device));
     { int rc_ = amc_flush(c); if (rc_) return rc_; }
     if (c->n > 0) {
-        hipLaunchKernelGGL(k_ic, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->S, c->P, *cfg, (long long)c->n);
+        AMC_LAUNCH(c, k_ic, dim3((unsigned)((c->n + 255) / 256)), dim3(256), c->S, c->P, *cfg, (long long)c->n);
         AMC_HIP(c, hipGetLastError());
     }
     c->uploaded = true;

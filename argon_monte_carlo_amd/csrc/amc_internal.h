@@ -1,6 +1,7 @@
 // amc_internal.h — host-side context of libargonmc.so and the launcher prototypes shared by its translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -180,6 +181,8 @@ struct amc_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     std::vector<std::pair<int, int>> ev_pending;   // (kernel class, pool index)
     size_t ev_used;
+    hipEvent_t prof_ev0, prof_ev1;  // the open bracket's events (nullptr outside a bracket / when not profiling): AMC_LAUNCH
+                                    // attaches them to the dispatch itself
     // multi-GPU
     bool mg_count_pp;              // this rank adds the p-p collision count to its counters
     volatile int *h_host_ncand;    // host-mapped word written by k_resolve (candidate count of the last sweep)
@@ -209,6 +212,15 @@ int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
         if (e__ != hipSuccess) return amc_fail((c), AMC_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
                                                hipGetErrorString(e__), __FILE__, __LINE__);                   \
     } while (0)
+
+// Every kernel of the step is launched through AMC_LAUNCH.  Inside an open profiling bracket the launch carries the
+// bracket's two events ON THE DISPATCH (hipExtLaunchKernelGGL: start = the kernel begins to execute, stop = it has
+// finished) — the same begin / end timestamps rocprofv3 --kernel-trace reports, so bench.py's per-kernel figures agree
+// with the committed kernel statistics and their sum stays below the step time (events recorded around a launch with
+// hipEventRecord also count the dispatch gap in front of it: 2-4 us per kernel, which made the classes of the round-2
+// line add up to more than the step).  Outside a bracket both events are null: a plain launch.
+#define AMC_LAUNCH(c, kernel, grid, block, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, (c)->stream, (c)->prof_ev0, (c)->prof_ev1, 0, __VA_ARGS__)
 
 // profiling brackets
 void amc_prof_begin(amc_ctx *c, int kclass);

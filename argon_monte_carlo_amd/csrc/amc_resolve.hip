@@ -528,7 +528,7 @@ template <int GEOM>
 static void rs_launch_all(amc_ctx *c, const rs_args &A)
 {
     if (c->allpairs) {
-        hipLaunchKernelGGL((k_resolve<GEOM, 2>), dim3(1), dim3(RS_T), 0, c->stream, A);
+        AMC_LAUNCH(c, (k_resolve<GEOM, 2>), dim3(1), dim3(RS_T), A);
         return;
     }
     // grid mode: every small component wide first (emulation + its own validation), then the ordered workgroup for what
@@ -550,13 +550,13 @@ static void rs_launch_all(amc_ctx *c, const rs_args &A)
     amc_launch_clusters_wide(c, Aw);
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_RESOLVE);
-    hipLaunchKernelGGL((k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), 0, c->stream, Aw);
+    AMC_LAUNCH(c, (k_resolve<GEOM, 0>), dim3(1), dim3(RS_T), Aw);
     // the commit: deferred results -> it waits for the next streaming pass (or amc_flush); else a kernel of its own, now
     c->commit_defer = A.defer_commit != 0;
     if (A.defer_commit) { c->commit_pending = true; return; }
     amc_prof_end(c);
     amc_prof_begin(c, AMC_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), 0, c->stream, Aw);
+    AMC_LAUNCH(c, k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), Aw);
 }
 
 static rs_args rs_make_args(amc_ctx *c)
@@ -585,7 +585,7 @@ hipError_t amc_launch_commit(amc_ctx *c)
     rs_args A = rs_make_args(c);
     A.defer_commit = c->commit_defer ? 1 : 0;
     amc_prof_begin(c, AMC_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), 0, c->stream, A);
+    AMC_LAUNCH(c, k_commit, dim3(AMC_COMMIT_BLOCKS), dim3(256), A);
     amc_prof_end(c);
     return hipGetLastError();
 }
@@ -594,7 +594,7 @@ hipError_t amc_launch_apply(amc_ctx *c)
 {
     rs_args A = rs_make_args(c);
     A.apply_only = 1;
-    hipLaunchKernelGGL(k_commit, dim3(8), dim3(256), 0, c->stream, A);
+    AMC_LAUNCH(c, k_commit, dim3(8), dim3(256), A);
     return hipGetLastError();
 }
 

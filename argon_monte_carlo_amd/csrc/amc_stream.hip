@@ -193,15 +193,15 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     amc_prof_begin(c, (stages == AMC_ST_BOUNDS) ? AMC_K_BOUNDS : AMC_K_DRIFT_WALLS);
     switch (c->P.geometry) {
     case AMC_GEOM_CUBE:
-        hipLaunchKernelGGL(k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
+        AMC_LAUNCH(c, k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(threads), c->S, c->P, c->out, dt,
                            stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     case AMC_GEOM_PORE:
-        hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P, c->out, dt,
+        AMC_LAUNCH(c, k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(threads), c->S, c->P, c->out, dt,
                            stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     case AMC_GEOM_PORE_ENERGISED:
-        hipLaunchKernelGGL(k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), 0, c->stream, c->S, c->P,
+        AMC_LAUNCH(c, k_stream<AMC_GEOM_PORE_ENERGISED>, dim3(blocks), dim3(threads), c->S, c->P,
                            c->out, dt, stages, c->lo, c->hi, kp, bounds_slot, c->G, c->B, build, L, C);
         break;
     default:

@@ -75,22 +75,24 @@ def make_workload(name, n_override=None, device=0):
 
 
 def host_cores():
-    """Host cores this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one.  A GPU box
-    shows all of its (hundreds of) cores to a job that owns a share of them: without a visible limit the count is capped at
-    16, the share that goes with one GPU on the measurement boxes (AMC_BENCH_CORES overrides)."""
+    """(cores, source): host cores this process may really use — the affinity mask, cut by a cgroup CPU quota if there is
+    one ("affinity" / "cgroup").  A GPU box shows all of its (hundreds of) cores to a job that owns a share of them:
+    without a visible limit the count is capped at 16, the share that goes with one GPU on the measurement boxes, and the
+    source says "assumed" (AMC_BENCH_CORES overrides: "env")."""
     if os.environ.get("AMC_BENCH_CORES"):
-        return max(1, int(os.environ["AMC_BENCH_CORES"]))
+        return max(1, int(os.environ["AMC_BENCH_CORES"])), "env"
+    src = "affinity"
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            n = min(n, max(1, int(int(q) / int(per))))
+        if q != "max" and int(int(q) / int(per)) < n:
+            n, src = max(1, int(int(q) / int(per))), "cgroup"
     except (OSError, ValueError):
         pass
-    return n if n <= 64 else 16
+    return (n, src) if n <= 64 else (16, "assumed")
 
 
 def cpu_baseline(workload, budget_s=12.0):
@@ -105,7 +107,7 @@ def cpu_baseline(workload, budget_s=12.0):
     from oracle import oracle as O
     p, c, init = make_workload(workload)
     kind = WORKLOADS[workload][0]
-    ncores = host_cores()
+    ncores, cores_src = host_cores()
 
     def timed(one, budget):
         one()                                       # warm-up (page faults)
@@ -128,7 +130,7 @@ def cpu_baseline(workload, budget_s=12.0):
     else:
         one = lambda: orc.timestep(c["dt"])                             # noqa: E731
     steps, el = timed(one, budget_s)
-    serial = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+    serial = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": 1, "cores_source": "single thread", "kind": "port",
               "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle/amc_oracle.c single thread"}
     out = {"cpu_baseline_1core": serial}
     if kind == "temp":
@@ -137,7 +139,7 @@ def cpu_baseline(workload, budget_s=12.0):
     par = O.Oracle(p, mode="mul")
     par.upload(*init)
     steps, el = timed(lambda: par.timestep_par(c["dt"], threads=ncores), budget_s)
-    allc = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
+    allc = {"value": p.n * steps / el, "unit": "particle-steps/s", "cores": ncores, "cores_source": cores_src, "kind": "port",
             "sample": f"{steps} steps of {workload} (N={p.n}) in {el:.1f} s, oracle sweep with OpenMP threads over the "
                       "disjoint cells of a colour group" + (" (the Pore script's colouring on the cube's cells: NOT the "
                       "reference's serial cube order)" if kind == "cube" else " (= the reference's Pool.starmap structure)")}
@@ -156,7 +158,7 @@ def cpu_baseline_python_mp(n=100_000, steps=3):
     from oracle import pymp_structure as PM
     p, c = PR.pore_params(n=n)
     init = IC.pore_ic(p, c, seed=17)
-    ncores = host_cores()
+    ncores, cores_src = host_cores()
     s = PM.PyMpStepper(p, workers=ncores + 1)           # the reference's Pool(cpu_count() + 1) on the cores this job has
     s.upload(*init)
     t0 = time.perf_counter()
@@ -164,10 +166,70 @@ def cpu_baseline_python_mp(n=100_000, steps=3):
     for _ in range(steps):
         npp += s.timestep(c["dt"])["n_pp"]
     el = time.perf_counter() - t0
-    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": ncores, "cores_source": cores_src, "kind": "port",
             "workers": ncores + 1,
             "sample": f"{steps} steps (no warm-up) of the specular pore at N={n} in {el:.1f} s, {npp} p-p collisions; "
                       "oracle/pymp_structure.py (NumPy-scalar pair loop, full per-cell boolean masks, fresh Pool per colour group)"}
+
+
+def class_report(kt, steps, n_total, n_local, value_per_gpu, profiled_ms_per_step):
+    """Kernel-class times of the profiled repeat of the timed steps.  `per_kernel_avg_us` is microseconds PER STEP (total
+    time of the class / steps: a class launched three times in 2,000 steps weighs next to nothing), the per-launch averages
+    and launch counts are beside it; the durations come from events carried by the dispatches themselves (kernel begin ->
+    kernel end, what rocprofv3 --kernel-trace reports), so the classes add up to no more than the step."""
+    per_step = {k: v[0] * 1e3 / steps for k, v in kt.items() if v[1]}
+    out = {"per_kernel_avg_us": per_step,
+           "per_kernel_avg_launch_us": {k: v[0] * 1e3 / v[1] for k, v in kt.items() if v[1]},
+           "per_kernel_launches_per_step": {k: v[1] / steps for k, v in kt.items() if v[1]},
+           "per_kernel_timing": "dispatch-attached HIP events (hipExtLaunchKernelGGL start/stop) on the launch stream, profiled repeat of the timed steps",
+           "profiled_pass_ms_per_step": profiled_ms_per_step,
+           "whole_step_frac_of_hbm_peak": BYTES_PER_PARTICLE_STEP * value_per_gpu / 1e9 / HBM_PEAK_GBS}
+    # the whole pair sweep (list build outside the streaming pass, detect, wide clusters, ordered workgroup, commit)
+    # against its 24 B per particle, and the streaming pass against its 137 B: the two numbers the north star names
+    sweep_us = sum(v for kk, v in per_step.items() if kk in SWEEP_CLASSES)
+    if sweep_us > 0:
+        g = 24.0 * n_total / (sweep_us * 1e-6) / 1e9
+        out["pair_sweep"] = {"avg_us": sweep_us, "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 24}
+    if per_step.get("drift_walls"):
+        g = 137.0 * n_local / (per_step["drift_walls"] * 1e-6) / 1e9
+        out["streaming_pass"] = {"avg_us": per_step["drift_walls"], "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 137}
+    return out
+
+
+def extra_workload(name, steps, warmup, device, stream_ptr, sync):
+    """One more single-GPU workload timed in the same invocation (GPU legs only): the driver's record then covers both
+    sizes BASELINE.json's metric names.  Same protocol as the headline: warm-up, K timed steps between synchronisations,
+    then the K steps again with the per-kernel events."""
+    from argon_monte_carlo_amd.engine import Engine
+    p, c, init = make_workload(name, device=device)
+    eng = Engine(p)
+    eng.set_stream(stream_ptr)
+    eng.upload(*init)
+    eng.run(c["dt"], warmup)
+    sync()
+    t0 = time.perf_counter()
+    stats = eng.run(c["dt"], steps)
+    sync()
+    el = time.perf_counter() - t0
+    eng.profile(True)
+    t0 = time.perf_counter()
+    eng.run(c["dt"], steps)
+    sync()
+    el_prof = time.perf_counter() - t0
+    kt = eng.kernel_times()
+    eng.profile(False)
+    n = int(p.n)
+    value = n * steps / el
+    rep = class_report(kt, steps, n, n, value, el_prof / steps * 1e3)
+    out = {"workload": name, "geometry": WORKLOADS[name][0], "n_particles": n, "steps": steps, "warmup": warmup,
+           "ms_per_step": el / steps * 1e3, "value": value, "unit": "particle-steps/s",
+           "pp_collisions_per_step": stats["n_pp"] / steps if stats else None,
+           "whole_step_frac": rep["whole_step_frac_of_hbm_peak"],
+           "pair_sweep_frac": rep.get("pair_sweep", {}).get("frac"),
+           "streaming_pass_frac": rep.get("streaming_pass", {}).get("frac"),
+           "per_kernel_avg_us": rep["per_kernel_avg_us"], "per_kernel_avg_launch_us": rep["per_kernel_avg_launch_us"]}
+    del eng
+    return out
 
 
 def committed_traffic(workload, kclass, tag):
@@ -214,13 +276,16 @@ def spawn_ranks(n):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--round-tag", default="r02", help="prefix of the committed profile files to take `traffic` from")
+    ap.add_argument("--round-tag", default="r03", help="prefix of the committed profile files to take `traffic` from")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="cube_1e5", choices=sorted(WORKLOADS))
     ap.add_argument("--n", type=int, default=0, help="override the particle count per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-workloads", default="auto",
+                    help="comma-separated single-GPU workloads timed after the headline one (GPU legs only) and attached as "
+                         "`extra_workloads`; auto = cube_1e6,pore_1e6 behind the default headline on one GPU; none = skip")
     ap.add_argument("--no-python-mp-baseline", action="store_true", help="skip the NumPy + multiprocessing leg (~30 s)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: all ranks share GPU 0")
@@ -368,8 +433,10 @@ def main():
     eng0.profile(True)
     if driver is not None:
         driver.profile_collective(True)
+    t0 = time.perf_counter()
     step(args.steps)
     sync()
+    el_prof = time.perf_counter() - t0
     kt = eng0.kernel_times()
     eng0.profile(False)
     if driver is not None:
@@ -386,7 +453,6 @@ def main():
         if dom[0] is not None:
             k, (ms, cnt) = dom
             avg_s = ms / cnt * 1e-3
-            avg_us = {kk: (vv[0] / vv[1] * 1e3 if vv[1] else None) for kk, vv in kt.items() if vv[1]}
             allpairs = "allpairs" in args.workload
             if k == "detect" and allpairs:
                 # the all-pairs detector: fp64 vector work, 9 flop per unordered pair
@@ -416,17 +482,7 @@ def main():
                         "algorithmic_bytes_per_launch": per_particle * units}
                 if k in ("clusters_wide", "resolve", "commit"):
                     roof["note"] = "latency-bound kernel (dependent scattered round trips on a few hundred candidates): priced at the pair sweep's 24 B per particle"
-            roof["per_kernel_avg_us"] = avg_us
-            roof["whole_step_frac_of_hbm_peak"] = BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS
-            # the whole pair sweep (list build outside the streaming pass, detect, wide clusters, ordered workgroup, commit)
-            # against its 24 B per particle, and the streaming pass against its 137 B: the two numbers the north star names
-            sweep_us = sum(v for kk, v in avg_us.items() if kk in SWEEP_CLASSES and v)
-            if sweep_us > 0:
-                g = 24.0 * n_total / (sweep_us * 1e-6) / 1e9
-                roof["pair_sweep"] = {"avg_us": sweep_us, "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 24}
-            if avg_us.get("drift_walls"):
-                g = 137.0 * n_local / (avg_us["drift_walls"] * 1e-6) / 1e9
-                roof["streaming_pass"] = {"avg_us": avg_us["drift_walls"], "achieved_GBps": g, "frac": g / HBM_PEAK_GBS, "bytes_per_particle": 137}
+            roof.update(class_report(kt, args.steps, n_total, n_local, value / world, el_prof / args.steps * 1e3))
         if roof is not None and roof["bound"] == "hbm":
             roof["traffic"], roof["traffic_source"] = committed_traffic(args.workload, roof["kernel_class"], args.round_tag)
         out = {
@@ -438,6 +494,11 @@ def main():
                        "pp_collisions_per_step": stats["n_pp"] / args.steps if stats else None},
             "roofline": roof,
         }
+        extras = args.extra_workloads
+        if extras == "auto":
+            extras = "cube_1e6,pore_1e6" if (world == 1 and not args.force_sharded and args.workload == "cube_1e5" and not args.n) else "none"
+        if extras != "none" and world == 1:
+            out["extra_workloads"] = [extra_workload(w, args.steps, args.warmup, local_rank, stream_ptr, sync) for w in extras.split(",") if w]
         if world == 1 and not args.no_cpu_baseline:
             out.update(cpu_baseline(args.workload))
             if not args.no_python_mp_baseline:
