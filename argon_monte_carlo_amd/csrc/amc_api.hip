@@ -321,6 +321,9 @@ int amc_create(amc_ctx **out, const amc_params *p)
             CK(hipMemsetAsync(c->w_slab, 0, total, c->stream));
             carve(c->w_slab);
         }
+        // AMC_MAX_HIST (diagnostic): the history / overlay entries a sweep may USE (the allocation keeps its size): lets a test
+        // drive the wide kernel's overlay protocol into its capacity limit at sizes the oracle handles in seconds
+        if (const char *e = getenv("AMC_MAX_HIST")) { const int v = atoi(e); if (v > 0 && v < W.max_hist) W.max_hist = v; }
         { amc_resolve_ctl z; memset(&z, 0, sizeof z); z.cur_round = 1; CK(hipMemcpyAsync(W.wctl, &z, sizeof z, hipMemcpyHostToDevice, c->stream)); CK(hipStreamSynchronize(c->stream)); }
         c->sweep_epoch = 0;
         CK(hipMemsetAsync(W.slot_of, 0xff, sizeof(int) * std::max<size_t>(n, 1), c->stream));

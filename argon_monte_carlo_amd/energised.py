@@ -240,7 +240,11 @@ class SurfaceEnergies:
     """surface_energy_cold / surface_energy_hot (Temp:80-84) and surface_energy_gap(z) (Temp:143-152) via mpmath,
     rounded to double (mpmath works at 53 bits there, so the mpf values ARE doubles)."""
 
-    def __init__(self, consts):
+    def __init__(self, consts, start_workers=False):
+        """``start_workers``: fork the gap-energy worker processes NOW instead of at the first case with several gap hits —
+        what a driver does that builds this object BEFORE its GPU context (sim.TemperatureSimulation, bench.py,
+        tests/soak.py): the workers are then forked from a process that has not initialised HIP, and nothing of a GPU
+        runtime (threads' locks, mapped device memory) is inherited by them."""
         from mpmath import exp, quad
         self._quad = quad
         self._integrand = lambda x: (x ** 3) / (exp(x) - 1)                  # Temp:80
@@ -260,6 +264,8 @@ class SurfaceEnergies:
         self.cold_mpf = 9 * self.t_cold * self.n_graphene * self.boltzman * (self.t_cold / self.t_debye_graphene) ** 3 * q_cold
         self.hot_mpf = 9 * self.t_hot * self.n_graphene * self.boltzman * (self.t_hot / self.t_debye_graphene) ** 3 * q_hot
         self.cold, self.hot = float(self.cold_mpf), float(self.hot_mpf)
+        if start_workers:
+            self._get_pool()
 
     # ---- several gap energies at once ---------------------------------------------------------------------------------
     # One mpmath.quad costs 0.7-1.5 ms of pure-Python multiprecision arithmetic and a step at N = 1e6 has about five gap

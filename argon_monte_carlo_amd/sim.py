@@ -188,7 +188,8 @@ class TemperatureSimulation(Simulation):
         self.kind = "temp"
         self.params, self.consts = params, consts
         self.dt = consts["dt"]
-        self.energies = SurfaceEnergies(consts)
+        # (the gap-energy workers are forked here, ahead of amc_create: no child of this process inherits a HIP context)
+        self.energies = SurfaceEnergies(consts, start_workers=True)
         params.E_cold, params.E_hot = self.energies.cold, self.energies.hot
         self.engine = EnergisedEngine(params)
         self.sampler = DirectionSampler(np_rng, py_rng)

@@ -305,6 +305,13 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    energies_early = None
+    if WORKLOADS[args.workload][0] == "temp":
+        # the gap-energy worker processes (energised.py) are forked before this process initialises the GPU
+        from argon_monte_carlo_amd import params as PR_
+        from argon_monte_carlo_amd.energised import SurfaceEnergies
+        energies_early = SurfaceEnergies(PR_.pore_params(n=args.n or WORKLOADS[args.workload][1], energised=True)[1], start_workers=True)
+
     import torch
     import torch.distributed as dist
 
@@ -344,7 +351,8 @@ def main():
         n_total = n_per_gpu if args.strong else n_per_gpu * world       # weak scaling (default): per-GPU particles fixed
         p, c, init = make_workload(args.workload, n_total, device=local_rank)
         p.reserved0 |= 1
-        p.E_cold, p.E_hot = SurfaceEnergies(c).cold, SurfaceEnergies(c).hot          # Temp:83-84
+        energies = energies_early
+        p.E_cold, p.E_hot = energies.cold, energies.hot          # Temp:83-84
         if sharded:
             from argon_monte_carlo_amd.dist import ShardedTemperatureSimulation
             eng = ShardedTemperatureSimulation(p, rank, world, backend=args.backend, stream_ptr=stream_ptr)
@@ -354,7 +362,6 @@ def main():
             eng.set_stream(stream_ptr)
         eng.upload(*init)
         sampler = DirectionSampler(np.random.RandomState(17), random.Random(17))     # same streams on every rank
-        energies = SurfaceEnergies(c)
 
         p_dev = None
         if args.device_rng:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ from the REFERENCE ITSELF (build container only).
 
-    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py [--only func|cube|pore|consts]
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python3 oracle/gen_golden.py [--only func|cube|pore|temp|consts|cube_natural|pore_natural]
 
 * function level: imports /root/reference/Open_Air_Pore_MC.py (its main loop is __main__-guarded) and calls
   pairwise_particles_in_cell / hit_vertical_wall / hit_cylinder_side_wall / num_out_of_bounds on seeded inputs.
@@ -269,7 +269,9 @@ HOOK = r'''
 import sys, numpy as np
 _KEYS = %r
 _snap_steps = set(%r)
+_hash_all = %r
 _store = {}
+_prev = {}
 def dump(step, ncoll=None, lists=None):
     m = sys.modules['__main__']
     g = m.__dict__
@@ -279,6 +281,22 @@ def dump(step, ncoll=None, lists=None):
     if step in _snap_steps:
         for k in _KEYS:
             _store['s%%04d_%%s' %% (step, k)] = arr(k)
+    if _hash_all:
+        # natural-size runs: SHA-256 of every state array after every step instead of the arrays (49 MB per snapshot at
+        # N = 557,649), plus the indices of the particles whose velocity changed in the step (the step's event set)
+        import hashlib
+        ch = None
+        for k in _KEYS:
+            a = arr(k)
+            a = a.astype(np.uint8) if a.dtype == bool else np.ascontiguousarray(a, dtype=np.float64)
+            _store['h%%04d_%%s' %% (step, k)] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+            if k.endswith('_velocities'):
+                if k in _prev:
+                    d = a != _prev[k]
+                    ch = d if ch is None else (ch | d)
+                _prev[k] = a
+        if ch is not None:
+            _store['ev%%04d' %% step] = np.nonzero(ch)[0].astype(np.int32)
     if step == -1:
         import random as _r
         st = np.random.get_state()
@@ -321,7 +339,7 @@ def _indent_of(line):
     return line[:len(line) - len(line.lstrip())]
 
 
-def run_patched(script, subs, inserts, snap_steps, out_name, meta, timeout=3600):
+def run_patched(script, subs, inserts, snap_steps, out_name, meta, timeout=3600, hash_all=False):
     """inserts: list of (regex of anchor line, 'before'|'after', code string using the anchor's indentation)."""
     work = tempfile.mkdtemp(prefix="amc_golden_", dir="/tmp")
     try:
@@ -341,7 +359,7 @@ def run_patched(script, subs, inserts, snap_steps, out_name, meta, timeout=3600)
         with open(os.path.join(work, "patched.py"), "w") as f:
             f.write("\n".join(lines))
         with open(os.path.join(work, "_golden_hook.py"), "w") as f:
-            f.write(HOOK % (STATE_KEYS, sorted(snap_steps)))
+            f.write(HOOK % (STATE_KEYS, sorted(snap_steps), bool(hash_all)))
         shutil.copy(os.path.join(REF, "utils.py"), os.path.join(work, "utils.py"))
         env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1")
         r = subprocess.run([sys.executable, "-u", "patched.py"], cwd=work, env=env, stdout=subprocess.PIPE,
@@ -423,6 +441,60 @@ def gen_cube(tag, K, sigma_mult, steps, snaps):
                 f"step_cube_{tag}.npz", dict(K=K, sigma_mult=sigma_mult, steps=steps))
 
 
+def gen_cube_natural(steps=30):
+    """Open_Air_Cube_MC.py AS WRITTEN (N = 24,627, sigma x 1, dt = tau / 25) except the loop bound and the dump hook:
+    initial state in full, then per step the counters, the SHA-256 of every state array and the event set."""
+    subs = [(r"^    for i in range\(num_timesteps\):", f"    for i in range({steps}):")]
+    inserts = [
+        (r"^    for i in range\(\d+\):", "before", "_step = -1\n_golden_hook.dump(-1)"),
+        (r"^        print\('  timestep',i,'of',num_timesteps", "before", "_step += 1"),
+        (r"^        print\('    ',N_collisions,' collisions'\)", "after",
+         "_golden_hook.dump(_step, N_collisions, [completed_paths[sim]])"),
+        (r"^    #generate figure for graphing", "before",
+         "_golden_hook.finish([completed_paths[sim], completed_x_paths[sim], completed_y_paths[sim], "
+         "completed_z_paths[sim]], dict(dt=dt, collision_range=collision_range, num_molecules=num_molecules))\nraise SystemExit(0)"),
+    ]
+    run_patched("Open_Air_Cube_MC.py", subs, inserts, {-1}, "step_cube_natural.npz",
+                dict(K=-1, sigma_mult=1, steps=steps, natural=1), hash_all=True)
+
+
+def gen_pore_natural(steps=3):
+    """Open_Air_Pore_MC.py AS WRITTEN (N = 557,649, sigma = 3.6e-19, its own initial conditions from np.random.seed(17) /
+    seed(17)) except the loop bound and the dump hook.  The initial state is NOT stored (27 MB of random doubles): its
+    SHA-256 is, and tests/natural_ic.py regenerates it from the same seeds with the same library calls (the recipe is
+    checked against the hashes before anything is compared).  About a minute per step in the build container."""
+    subs = [(r"^        for i in range\(num_timesteps\):", f"        for i in range({steps}):")]
+    inserts = [
+        (r"^        for i in range\(\d+\):", "before", "_golden_hook.dump(-1)"),
+        (r"^            print\('   ',num_collisions_per_step\.value,' collisions from this timestep'\)", "after",
+         "_golden_hook.dump(i, num_collisions_per_step.value, [completed_paths])"),
+        (r"^        print\('Num of measured full paths total: '", "after",
+         "_golden_hook.finish([completed_paths, completed_x_paths, completed_y_paths, completed_z_paths], "
+         "dict(dt=dt, collision_range=collision_range, total_cols=total_cols, num_molecules=num_molecules))"),
+    ]
+    run_patched("Open_Air_Pore_MC.py", subs, inserts, set(), "step_pore_natural.npz",
+                dict(K=-1, sigma_mult=1, slice=1000, steps=steps, natural=1), hash_all=True, timeout=7200)
+
+
+def gen_graph_hist():
+    """The one physics artefact the reference holds: the 200-bin cube free-path histogram pasted into graph_sim_data.py
+    (x_data = bin left edges, y_data = density over 423,143 paths).  Only the two arrays are taken — evaluated from the
+    two assignments, nothing else of the script is run — plus the exponential fit the script itself performs on them."""
+    from scipy.optimize import curve_fit
+    src = open(os.path.join(REF, "graph_sim_data.py")).read()
+    a = src.index("x_data = [")
+    b = src.index("#Intended curve for fitting")
+    ns = {"np": np}
+    exec(compile(src[a:b], "<graph-hist-arrays>", "exec"), ns)
+    x, y = np.asarray(ns["x_data"], dtype=np.float64), np.asarray(ns["y_data"], dtype=np.float64)
+    assert x.shape == y.shape == (200,)
+    popt, _ = curve_fit(lambda t, p, q: p * np.exp(q * np.array(t)), x, y, p0=[14.0, -11.0], maxfev=25000)
+    width = x[1] - x[0]
+    n_paths = int(round(1.0 / (y[y > 0].min() * width)))
+    np.savez_compressed(os.path.join(OUT, "graph_hist.npz"), x=x, density=y, fit_a=popt[0], fit_b=popt[1], n_paths=n_paths)
+    print("graph_hist.npz: fit a=%g b=%g -> decay length %.2f nm, %d paths" % (popt[0], popt[1], -1e9 / popt[1], n_paths))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -439,6 +511,13 @@ def main():
         gen_pore("a", K=1500, sigma_mult=100, slice_=1, steps=40, snaps=[0, 1, 5, 20, 39])
     if a.only in ("all", "temp"):
         gen_temp("a", K=2000, sigma_mult=100, slice_=1, steps=30, snaps=[0, 1, 10, 29])
+    # the reference's OWN parameters (minutes of run time: not part of "all")
+    if a.only in ("all", "graph_hist"):
+        gen_graph_hist()
+    if a.only == "cube_natural":
+        gen_cube_natural()
+    if a.only == "pore_natural":
+        gen_pore_natural()
 
 
 if __name__ == "__main__":

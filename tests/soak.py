@@ -2,7 +2,11 @@
 is compared bit for bit every `chunk` steps and the device histograms with np.histogram of the oracle's completed
 paths at the end.  Writes a JSON summary (committed under profiles/ as evidence).
 
-    python tests/soak.py pore_1e6 1000 100
+    python tests/soak.py pore_1e6 1000 100 [--cw-blocks 8]
+
+--cw-blocks K runs the wide cluster kernel with K waves instead of 512 (AMC_CW_BLOCKS): many clusters per wave, emulated
+in lockstep and sharing one work-item list — the configuration, not the step count, that exposed the one protocol bug of
+round 2; every soak of record runs once in it.
 """
 import json
 import os
@@ -16,6 +20,12 @@ from bench import make_workload
 from argon_monte_carlo_amd.engine import Engine
 from oracle import oracle as O
 
+cw_blocks = 0
+if "--cw-blocks" in sys.argv:
+    k = sys.argv.index("--cw-blocks")
+    cw_blocks = int(sys.argv[k + 1])
+    del sys.argv[k:k + 2]
+    os.environ["AMC_CW_BLOCKS"] = str(cw_blocks)        # (read when the context is created)
 workload = sys.argv[1] if len(sys.argv) > 1 else "pore_1e6"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 chunk = int(sys.argv[3]) if len(sys.argv) > 3 else 100
@@ -27,7 +37,7 @@ if temp:
     import random
     from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
     from argon_monte_carlo_amd.engine import EnergisedEngine
-    energies = SurfaceEnergies(c)
+    energies = SurfaceEnergies(c, start_workers=True)      # (forked before the engine's GPU context exists)
     p.reserved0 |= 1
     p.E_cold, p.E_hot = energies.cold, energies.hot
     eng = EnergisedEngine(p)
@@ -90,11 +100,11 @@ hist_equal = bool(npaths == len(paths))
 for row, key in enumerate(("total", "px", "py", "pz")):
     ref, _ = np.histogram(paths[key], bins=p.hist_bins, range=(p.hist_lo, p.hist_hi))
     hist_equal = hist_equal and bool(np.array_equal(counts[row], ref.astype(np.uint64)))
-out = {"workload": workload, "n": int(p.n), "steps": done, "compared_every": chunk, "state_bit_identical": ok,
+out = {"workload": workload, "n": int(p.n), "steps": done, "wide_kernel_waves": cw_blocks or 512, "compared_every": chunk, "state_bit_identical": ok,
        "first_difference": first_bad, "counters_equal": tot == otot, "counters": tot, "completed_paths": int(npaths),
        "histograms_equal_np_histogram_of_oracle_paths": hist_equal,
        "per_step_momentum_energy_sums_equal": (csv_equal if temp else None), "gpu_seconds": round(t_gpu, 3),
        "oracle_seconds_1_core": round(t_cpu, 1)}
 print(json.dumps(out))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open(f"gpurun_out/soak_{workload}_{done}.json", "w"), indent=1)
+json.dump(out, open(f"gpurun_out/soak_{workload}_{done}" + (f"_cw{cw_blocks}" if cw_blocks else "") + ".json", "w"), indent=1)

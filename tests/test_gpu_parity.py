@@ -936,6 +936,40 @@ def test_candidate_overflow_in_the_large_sweep_plan_is_reported(Engine):
     eng.close()
 
 
+def test_overlay_history_overflow_in_the_wide_kernel_is_reported(Engine, O, monkeypatch):
+    """The host-visible contract of the wide kernel's publish-then-probe protocol at its capacity limit: with fewer
+    history / overlay entries than the sweep's clusters need (AMC_MAX_HIST caps what a sweep may use), every step reports
+    AMC_ERR_CAPACITY — no hang, no crash, no silent loss of a collision — and the context stays usable: the state is
+    intact, and a context with the full work space resolves the same state and equals the oracle."""
+    from argon_monte_carlo_amd._lib import ArgonMCError
+    p, c = PR.cube_params_for_n(400_000)
+    init = IC.cube_ic(p, c, seed=127)
+    monkeypatch.setenv("AMC_MAX_HIST", "600")           # ~800 candidates per step own the entries 4k .. 4k + 3
+    eng = Engine(p)
+    monkeypatch.delenv("AMC_MAX_HIST")
+    eng.upload(*init)
+    for s in range(3):
+        with pytest.raises(ArgonMCError) as ei:
+            eng.timestep(c["dt"])
+        assert ei.value.code == -4, (s, ei.value)
+    st = eng.download()
+    assert all(np.all(np.isfinite(st[k])) for k in ("x", "y", "z", "vx", "vy", "vz"))
+    eng.close()
+    # the same workload with the full work space: equal to the oracle
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(*init)
+    orc.upload(*init)
+    for s in range(2):
+        st = eng.timestep(c["dt"])
+        rc, so = orc.timestep(c["dt"])
+        assert rc == 0 and st["n_pp"] == so["n_pp"] > 0
+    dev, ref = eng.download(), orc.state()
+    for k in ("x", "y", "z", "vx", "vy", "vz", "d"):
+        assert np.array_equal(dev[k], ref[k]), k
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- device-side initial conditions
 def test_device_initial_conditions_cube(Engine):
     """amc_init_synthetic, cube: the documented mapping of Philox numbers to positions / velocities

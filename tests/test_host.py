@@ -242,6 +242,30 @@ def test_gap_energies_in_worker_processes_equal_the_serial_ones(monkeypatch):
     assert en.gap_many(zs) == want and SurfaceEnergies._pool is None
 
 
+def test_gap_workers_can_be_started_ahead_of_the_gpu_context(monkeypatch):
+    """SurfaceEnergies(consts, start_workers=True) forks the workers in the constructor — the facade and bench.py build it
+    before amc_create, so no worker is ever forked from a process with an initialised HIP runtime — and gap_many then
+    uses exactly those processes."""
+    import inspect
+    from argon_monte_carlo_amd import sim as SIM
+    from argon_monte_carlo_amd.energised import SurfaceEnergies
+    _, c = PR.pore_params(n=100, energised=True)
+    monkeypatch.setenv("AMC_GAP_WORKERS", "2")
+    try:
+        en = SurfaceEnergies(c, start_workers=True)
+        assert SurfaceEnergies._pool is not None and SurfaceEnergies._pool.alive()
+        pids = [w[0] for w in SurfaceEnergies._pool.workers]
+        z0 = c["open_air_height"] + c["hot_coating_height"]
+        zs = [z0 + f * c["gap_height"] for f in (0.2, 0.6)]
+        assert en.gap_many(zs) == [en.gap(z) for z in zs]
+        assert [w[0] for w in SurfaceEnergies._pool.workers] == pids        # the early workers served the case
+    finally:
+        SurfaceEnergies._shutdown_pool()
+    # the facade creates the energies (and their workers) before the engine
+    src = inspect.getsource(SIM.TemperatureSimulation.__init__)
+    assert 0 < src.index("SurfaceEnergies(consts, start_workers=True)") < src.index("EnergisedEngine(params)")
+
+
 def test_gap_energies_survive_a_dead_worker(monkeypatch):
     """A worker that went away (killed, out of memory) must not cost the step: gap_many notices, does the integrals in
     this process and stops using workers."""
