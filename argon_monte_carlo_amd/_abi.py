@@ -91,4 +91,4 @@ def path_record_dtype():
 
 
 AMC_K_NAMES = ["drift_walls", "bin_count", "bin_scan", "bin_scatter", "detect", "resolve", "bounds", "validate",
-               "resolve_more", "commit", "clusters_wide", "other11"]
+               "resolve_more", "commit", "clusters_wide", "fixup"]

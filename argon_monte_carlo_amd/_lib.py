@@ -65,6 +65,7 @@ SIGNATURES = {
     "amc_profile": (C.c_int, [_ctx, C.c_int]),
     "amc_kernel_times": (C.c_int, [_ctx, _dp, _i64p]),
     "amc_kernel_name": (C.c_char_p, [C.c_int]),
+    "amc_overlap_stats": (C.c_int, [_ctx, _i64p]),
 }
 
 

@@ -161,7 +161,7 @@ const char *amc_last_error(const amc_ctx *ctx) { return ctx ? ctx->err.c_str() :
 const char *amc_kernel_name(int k)
 {
     static const char *names[AMC_K_COUNT] = {"drift_walls", "bin_count", "bin_scan",     "bin_scatter", "detect",  "resolve",
-                                             "bounds",      "validate",  "resolve_more", "commit",      "clusters_wide", "other11"};
+                                             "bounds",      "validate",  "resolve_more", "commit",      "clusters_wide", "fixup"};
     return (k >= 0 && k < AMC_K_COUNT) ? names[k] : "?";
 }
 
@@ -170,8 +170,9 @@ void amc_destroy(amc_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    void *ptrs[] = {c->s_slab, c->d_lay, c->B.rec, c->B.head, c->W.ov_head, c->w_slab, c->d_rec, c->d_hist,
-                    c->d_edges, c->d_cnt, c->d_banks, c->d_dbg};
+    void *ptrs[] = {c->s_slab, c->s_slab2, c->d_lay, c->B_buf[0].rec, c->B_buf[0].head, c->B_buf[1].rec, c->B_buf[1].head,
+                    c->extra_buf[0], c->extra_count, c->wev_buf[0].rec, c->wev_buf[0].count, c->ovl_flags,
+                    c->W.ov_head, c->w_slab, c->d_rec, c->d_hist, c->d_edges, c->d_cnt, c->d_banks, c->d_dbg};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -184,6 +185,9 @@ void amc_destroy(amc_ctx *c)
     if (c->kin_recv) hipFree(c->kin_recv);
     if (c->kin_vpub) hipFree(c->kin_vpub);
     for (auto &pr : c->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (c->ev_detect) hipEventDestroy(c->ev_detect);
+    if (c->ev_stream) hipEventDestroy(c->ev_stream);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -219,6 +223,17 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(c->k_ms, 0, sizeof c->k_ms);
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
+    memset(c->S_buf, 0, sizeof c->S_buf); memset(c->B_buf, 0, sizeof c->B_buf); memset(c->wev_buf, 0, sizeof c->wev_buf);
+    c->s_slab2 = nullptr; c->extra_buf[0] = c->extra_buf[1] = nullptr; c->extra_count = nullptr; c->max_extra = 0;
+    c->stream2 = nullptr; c->ev_detect = c->ev_stream = nullptr;
+    c->ovl_flags = nullptr; c->ovl_tick = 0;
+    c->ovl_sync_values = !(getenv("AMC_OVERLAP_SYNC") && !strcmp(getenv("AMC_OVERLAP_SYNC"), "event"));
+    // AMC_OVERLAP: 1 the streaming pass of step s + 1 runs beside the resolve of sweep s inside amc_run, on a second stream;
+    // 2 the same kernels in order on one stream (debugging); 0 the plain sequence (the default: measured on MI355X the resolve
+    // kernels take twice as long beside the pass's memory traffic, which with the fix-up kernel and the two cross-stream
+    // dependencies of a step eats what the overlap hides — DESIGN 4.2 has the numbers)
+    c->overlap_mode = getenv("AMC_OVERLAP") ? atoi(getenv("AMC_OVERLAP")) : 0;
+    c->ovl_steps = 0;
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pre_case = -1; c->T.pin = nullptr;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
@@ -249,10 +264,16 @@ int amc_create(amc_ctx **out, const amc_params *p)
         CK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
         c->stream = c->own_stream;
         const size_t n = (size_t)c->n;
-        // detection mode: single cells and small N use the LDS-tiled all-pairs kernel
-        // (detect_mode 2 above 4096 particles: the all-pairs DETECTOR in front of the grid-based resolve — the kernel the
-        // reference's pairwise loop maps to directly, measurable at full size against the fp64 vector peak)
-        c->allpairs = (p->geometry == AMC_GEOM_CELL) || (p->detect_mode != 1 && c->n <= 4096);
+        // detection mode: only single cells (AMC_GEOM_CELL: no geometry to lay a grid over) run without the detection grid —
+        // all-pairs detector, brute-force validation, everything in the one ordered workgroup.  Cube and pore contexts use
+        // the grid and the wide cluster kernel at ANY size: measured at N = 4,096 the grid path takes 32 us per step, the
+        // gridless one 132 (N = 1,000: 28 against 45; round 2 sent N <= 4,096 down the gridless path).  AMC_ALLPAIRS_MAX_N
+        // restores a threshold for experiments.
+        // (detect_mode 2: the all-pairs DETECTOR in front of the same grid-based resolve — the kernel the reference's
+        // pairwise loop maps to directly, measurable at full size against the fp64 vector peak)
+        long long small_n = 0;
+        if (const char *e = getenv("AMC_ALLPAIRS_MAX_N")) small_n = atoll(e);
+        c->allpairs = (p->geometry == AMC_GEOM_CELL) || (p->detect_mode != 1 && c->n <= small_n);
         c->detect_ap = c->allpairs || p->detect_mode == 2;
         if (p->geometry == AMC_GEOM_CELL && p->detect_mode == 1) {
             rc = amc_fail(c, AMC_ERR_INVALID, "AMC_GEOM_CELL has no cell grid: detect_mode must be 0 or 2");
@@ -270,14 +291,18 @@ int amc_create(amc_ctx **out, const amc_params *p)
             size_t off = 0;
             for (auto pp : st) { *pp = (double *)(c->s_slab + off); off += per; }
             c->S.flag = (uint8_t *)(c->s_slab + off);
+            c->S_buf[0] = c->S;
         }
         if ((rc = setup_grid(c)) != AMC_OK) goto fail;
         if (!c->allpairs) {
             const size_t nc = (size_t)c->G.ncells;
-            CK(dalloc(&c->B.rec, n));
+            c->max_extra = AMC_EXTRA_NODES(c->n);
+            CK(dalloc(&c->B.rec, n + (size_t)c->max_extra));
             CK(dalloc(&c->B.head, nc + 1));
             CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
             c->B.epoch = 0;
+            c->B.n = (int)c->n; c->B.extra = nullptr;
+            c->B_buf[0] = c->B;
             CK(dalloc(&c->W.ov_head, nc));
             CK(hipMemsetAsync(c->W.ov_head, 0xff, sizeof(int) * std::max<size_t>(nc, 1), c->stream));
         }
@@ -313,7 +338,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
                 take(&W.edge_a, (size_t)W.max_edges); take(&W.edge_b, (size_t)W.max_edges);
                 take(&W.hist, (size_t)W.max_hist); take(&W.ov_next, (size_t)W.max_hist);
                 take(&W.ev_gen, (size_t)W.max_hist); take(&W.ev, (size_t)W.max_hist);
-                take(&W.adj_head, n); take(&W.slot_of, n);
+                take(&W.adj_head, n); take(&W.slot_of, n); take(&W.victim, n);
                 return (off + 255) & ~(size_t)255;
             };
             const size_t total = carve(nullptr);
@@ -582,13 +607,141 @@ int amc_timestep(amc_ctx *c, double dt, amc_step_stats *out)
     return amc_finish_stats(c, out);
 }
 
+// ---- the overlapped run -----------------------------------------------------------------------------------
+// Resolving a sweep is latency-bound work for a few hundred waves (k_clusters_wide, the ordered workgroup) and needs the
+// PRE-sweep state; the next step's streaming pass is bandwidth- and atomic-bound work for the whole chip and needs the sweep's
+// results only for the few thousand particles it touches.  Inside amc_run the two therefore run side by side: the pass reads
+// the state buffer the resolve reads and writes the other one, leaves out the particles of the sweep's candidates, and a
+// fix-up kernel advances those from the sweep's results afterwards (amc_stream.hip).  What is needed for it — a second set of
+// state arrays and per-cell lists, the deferred-event buffers, a second stream — is allocated by the first such run.
+static int ensure_overlap(amc_ctx *c)
+{
+    if (c->s_slab2) return AMC_OK;
+    const size_t n = (size_t)std::max<int64_t>(c->n, 1);
+    {
+        const size_t per = ((sizeof(double) * n) + 255) & ~(size_t)255;
+        const size_t total = 10 * per + ((n + 255) & ~(size_t)255);
+        AMC_HIP(c, hipMalloc((void **)&c->s_slab2, total));
+        AMC_HIP(c, hipMemsetAsync(c->s_slab2, 0, total, c->stream));
+        amc_state &T = c->S_buf[1];
+        double **st[] = {&T.x, &T.y, &T.z, &T.vx, &T.vy, &T.vz, &T.d, &T.dx, &T.dy, &T.dz};
+        size_t off = 0;
+        for (auto pp : st) { *pp = (double *)(c->s_slab2 + off); off += per; }
+        T.flag = (uint8_t *)(c->s_slab2 + off);
+        T.px = c->S_buf[0].px; T.py = c->S_buf[0].py; T.pz = c->S_buf[0].pz;      // (prior_*_vals are not kept by these runs)
+    }
+    {
+        const size_t nc = (size_t)c->G.ncells;
+        amc_lists &T = c->B_buf[1];
+        AMC_HIP(c, dalloc(&T.rec, n + (size_t)c->max_extra));
+        AMC_HIP(c, dalloc(&T.head, nc + 1));
+        AMC_HIP(c, hipMemsetAsync(T.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
+        T.epoch = 0; T.n = (int)c->n;
+        AMC_HIP(c, dalloc(&c->extra_buf[0], (size_t)2 * c->max_extra));
+        c->extra_buf[1] = c->extra_buf[0] + c->max_extra;
+        AMC_HIP(c, dalloc(&c->extra_count, 2));
+        AMC_HIP(c, hipMemsetAsync(c->extra_count, 0, 2 * sizeof(int), c->stream));
+    }
+    {
+        // deferred events of a pass: wall hits (~1e-3 per particle and step in the pore), by bank
+        const int cap = (int)std::max<long long>(1024, (long long)c->n / (4 * AMC_COUNTER_BANKS));
+        AMC_HIP(c, dalloc(&c->wev_buf[0].rec, (size_t)2 * AMC_COUNTER_BANKS * cap));
+        AMC_HIP(c, dalloc(&c->wev_buf[0].count, (size_t)2 * AMC_COUNTER_BANKS));
+        AMC_HIP(c, hipMemsetAsync(c->wev_buf[0].count, 0, sizeof(unsigned int) * 2 * AMC_COUNTER_BANKS, c->stream));
+        c->wev_buf[0].cap = c->wev_buf[1].cap = cap;
+        c->wev_buf[1].rec = c->wev_buf[0].rec + (size_t)AMC_COUNTER_BANKS * cap;
+        c->wev_buf[1].count = c->wev_buf[0].count + AMC_COUNTER_BANKS;
+    }
+    AMC_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess || !can) c->ovl_sync_values = 0;
+        AMC_HIP(c, dalloc(&c->ovl_flags, 64));
+        AMC_HIP(c, hipMemsetAsync(c->ovl_flags, 0, 64 * sizeof(unsigned int), c->stream));
+    }
+    AMC_HIP(c, hipEventCreateWithFlags(&c->ev_detect, hipEventDisableTiming));
+    AMC_HIP(c, hipEventCreateWithFlags(&c->ev_stream, hipEventDisableTiming));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    return AMC_OK;
+}
+
+static int run_overlapped(amc_ctx *c, double dt, int64_t nsteps)
+{
+    int rc = ensure_overlap(c);
+    if (rc) return rc;
+    if ((rc = amc_flush(c))) return rc;                 // the state is complete in the current arrays
+    const int g = c->P.geometry;
+    const bool two = c->overlap_mode == 1;
+    int cur = (c->S.x == c->S_buf[1].x) ? 1 : 0;
+    c->B_buf[cur] = c->B;                               // (the list epoch lives in the current copy)
+    c->B_buf[0].extra = c->extra_buf[0]; c->B_buf[1].extra = c->extra_buf[1];
+    unsigned int prev_epoch = 0;                        // the sweep in flight (none before the first step)
+    for (int64_t s = 0; s < nsteps; s++) {
+        int st = (g == AMC_GEOM_CUBE) ? (AMC_ST_DRIFT | AMC_ST_WALLS) : (AMC_ST_DRIFT | AMC_ST_WALLS | AMC_ST_BOUNDS);
+        if (g == AMC_GEOM_PORE && s > 0) st |= AMC_ST_BOUNDS_PRE;       // Pore:550 of the previous step
+        hipStream_t sp = two ? c->stream2 : c->stream;
+        if (two) {
+            // the pass may start once the previous sweep's detect kernel has marked its candidates' particles (and, at the
+            // first step, once everything queued before the run has finished)
+            c->ovl_tick++;
+            if (c->ovl_sync_values) {
+                AMC_HIP(c, hipStreamWriteValue32(c->stream, c->ovl_flags, c->ovl_tick, 0));
+                AMC_HIP(c, hipStreamWaitValue32(c->stream2, c->ovl_flags, c->ovl_tick, hipStreamWaitValueGte, 0xffffffffu));
+            } else {
+                AMC_HIP(c, hipEventRecord(c->ev_detect, c->stream));
+                AMC_HIP(c, hipStreamWaitEvent(c->stream2, c->ev_detect, 0));
+            }
+        }
+        if (s > 0) {
+            // (recorded above, BEHIND the detect kernel of step s - 1 and in front of its resolve kernels, which follow here)
+            AMC_HIP(c, amc_launch_resolve(c, true));
+        }
+        AMC_HIP(c, amc_launch_stream_ovl(c, dt, st, cur, prev_epoch, sp));
+        if (two) {
+            if (c->ovl_sync_values) {
+                AMC_HIP(c, hipStreamWriteValue32(c->stream2, c->ovl_flags + 16, c->ovl_tick, 0));
+                AMC_HIP(c, hipStreamWaitValue32(c->stream, c->ovl_flags + 16, c->ovl_tick, hipStreamWaitValueGte, 0xffffffffu));
+            } else {
+                AMC_HIP(c, hipEventRecord(c->ev_stream, c->stream2));
+                AMC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_stream, 0));
+            }
+        }
+        AMC_HIP(c, amc_launch_fixup(c, dt, st, cur, prev_epoch));
+        c->commit_pending = false; c->lazy_pending = false;             // (consumed by the fix-up kernel)
+        cur = 1 - cur;
+        c->S = c->S_buf[cur];
+        c->B = c->B_buf[cur];
+        AMC_HIP(c, amc_launch_detect(c));
+        prev_epoch = c->sweep_epoch;
+        c->out.step++;
+        c->ovl_steps++;
+    }
+    // the last sweep: resolved, and left to the plain machinery (its commit and its results wait for the next streaming pass,
+    // a flush or a read of the counters, as after any step)
+    AMC_HIP(c, amc_launch_resolve(c, true));
+    c->lazy_pending = true;
+    c->B_buf[cur] = c->B;
+    // the current lists' extra nodes die with them (the next build starts from the particles' own nodes)
+    AMC_HIP(c, hipMemsetAsync(c->extra_count, 0, 2 * sizeof(int), c->stream));
+    AMC_HIP(c, hipMemsetAsync(c->wev_buf[0].count, 0, sizeof(unsigned int) * 2 * AMC_COUNTER_BANKS, c->stream));
+    if (g == AMC_GEOM_PORE) AMC_HIP(c, amc_launch_stream(c, dt, AMC_ST_BOUNDS, 1));     // Pore:550 of the last step
+    return AMC_OK;
+}
+
 int amc_run(amc_ctx *c, double dt, int64_t nsteps, amc_step_stats *sum)
 {
     if (!c) return AMC_ERR_INVALID;
     if (!c->uploaded) return amc_fail(c, AMC_ERR_STATE, "amc_run before amc_upload");
     AMC_HIP(c, hipSetDevice(c->device));
+    const bool whole = c->lo == 0 && c->hi == c->n && !c->allpairs;
+    if (c->overlap_mode && whole && nsteps >= 2 && !c->keep_prior && !c->detect_ap && c->n > 0 &&
+        (c->P.geometry == AMC_GEOM_CUBE || c->P.geometry == AMC_GEOM_PORE)) {
+        int rc = run_overlapped(c, dt, nsteps);
+        if (rc) return rc;
+        return amc_finish_stats(c, sum);
+    }
     // inside the run only the last step needs its own post-sweep bounds pass (needs the whole range in one context)
-    const bool fold = c->P.geometry == AMC_GEOM_PORE && c->lo == 0 && c->hi == c->n && !c->allpairs;
+    const bool fold = c->P.geometry == AMC_GEOM_PORE && whole;
     for (int64_t s = 0; s < nsteps; s++) {
         int rc = enqueue_step(c, dt, fold && s > 0, fold && s + 1 < nsteps);
         if (rc) return rc;
@@ -763,6 +916,17 @@ int amc_profile(amc_ctx *c, int enable)
     hipSetDevice(c->device);
     amc_prof_collect(c);
     c->profiling = enable != 0;
+    return AMC_OK;
+}
+
+int amc_overlap_stats(amc_ctx *c, int64_t *out)
+{
+    if (!c || !out) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_dev_counters now;
+    int rc = amc_read_counters(c, &now);
+    if (rc) return rc;
+    out[0] = c->ovl_steps; out[1] = now.n_refiled; out[2] = c->overlap_mode; out[3] = c->max_extra;
     return AMC_OK;
 }
 

@@ -114,7 +114,7 @@ AMC_DEV void cw_probe_grid(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
     int q = amc_list_head(A.B, cell);
     while (q >= 0) {
         const amc_rec r = A.B.rec[q];
-        const int idx = q;
+        const int idx = amc_node_particle(A.B, q);
         q = amc_rec_next(r);
         double rx, ry, rz;
         amc_rec_pos(A.G, r, rx, ry, rz);
@@ -131,6 +131,7 @@ AMC_DEV void cw_probe_grid(const rs_args &A, rs_shared *wc, cw_lds &L, const cw_
             if (old == -1) {
                 const int s = s_off + atomicAdd(&wc->nslots, 1);
                 const int k = atomicAdd(&L.npull[own], 1);
+                W.victim[idx] = A.sweep_epoch;                  // (in no candidate: an overlapped streaming pass has advanced it)
                 if (s < W.max_slots && k < CW_PULLS) {
                     L.pull[own][k] = idx; L.psl[own][k] = s;   // (slot_of keeps the tag until the owner initialises the slot)
                     L.redo[own] = 1;

@@ -22,7 +22,7 @@ struct amc_dev_counters {
     unsigned int path_count;            // records currently in the path buffer
     unsigned int cand_count;            // candidate pairs of the current sweep
     int step;                           // current step index (for record keys)
-    int pad;
+    int n_refiled;                      // overlapped runs: particles advanced again from a sweep's result and filed under an extra node
 };
 
 // Per-event counters are BANKED: returning or not, atomics on one word from different waves complete one every ~12 ns
@@ -40,6 +40,22 @@ AMC_DEV int amc_bank_id()
     return __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 8u + (threadIdx.x >> 6)) & (AMC_COUNTER_BANKS - 1)));
 }
 
+// Deferred events of a streaming pass that runs AHEAD of the previous sweep's resolve (the overlapped run, amc_stream.hip):
+// a particle that the sweep pulls into a cluster after the pass has already advanced it is advanced again from its
+// collision result, so what the first, speculative pass emitted for it (wall paths, counters) must not count.  The pass
+// therefore appends its events here and the fix-up kernel commits them once it knows which particles were redone.
+// Banked (one counter word per (block, wave) bank: same-address atomics from many waves are a serial chain).
+struct amc_wev_rec {
+    int p, kind;                        // particle; 0 = completed path (a = phase), 1 = counters
+    int a, b;                           // kind 1: a = wall hits | failed solves << 16, b = out-of-bounds | previous step's << 16
+    double v[4];                        // kind 0: total, x, y, z
+};
+struct amc_wev {
+    amc_wev_rec *rec;                   // [AMC_COUNTER_BANKS][cap]
+    unsigned int *count;                // [AMC_COUNTER_BANKS]  (nullptr: events are applied directly)
+    int cap;
+};
+
 // where completed paths go: a record buffer (optional) + the four np.histogram-compatible histograms
 struct amc_out {
     amc_path_record *rec;               // nullptr: no records, histograms only
@@ -52,7 +68,16 @@ struct amc_out {
     double lo, hi;
     amc_dev_counters *cnt;
     int step;                           // index of the current step (record key), set by the host per launch
+    amc_wev wev;                        // count != nullptr: this pass's events are deferred (see amc_wev)
 };
+
+AMC_DEV void amc_wev_append(const amc_out &o, const amc_wev_rec &r)
+{
+    const int bank = amc_bank_id();
+    const unsigned int k = atomicAdd(&o.wev.count[bank], 1u);
+    if (k < (unsigned)o.wev.cap) o.wev.rec[(size_t)bank * o.wev.cap + k] = r;
+    else atomicOr(&o.cnt->flags, 4ULL);         // (work-space overflow: the step reports AMC_ERR_CAPACITY)
+}
 
 // np.histogram(a, bins=n, range=(lo,hi)) bin of one value (numpy/lib/_histograms_impl.py uniform-bin path):
 // returns -1 if outside [lo, hi].
@@ -73,6 +98,12 @@ AMC_DEV int amc_hist_bin(const amc_out &o, double v)
 AMC_DEV void amc_emit(const amc_out &o, int phase, long long cell, int i, int j, int which, double tot, double px,
                       double py, double pz)
 {
+    if (o.wev.count) {                  // a streaming pass ahead of the resolve: deferred (wall events: cell 0, j -1, which 0)
+        amc_wev_rec r;
+        r.p = i; r.kind = 0; r.a = phase; r.b = 0; r.v[0] = tot; r.v[1] = px; r.v[2] = py; r.v[3] = pz;
+        amc_wev_append(o, r);
+        return;
+    }
     amc_counter_bank &bank = o.banks[amc_bank_id()];
     atomicAdd(&bank.n_paths, 1ULL);
     atomicAdd(&bank.n_paths_total, 1ULL);

@@ -16,6 +16,8 @@
 //
 // A pair is emitted when d^2 < collision_range^2 * (1 + 1e-9): a superset of the reference's
 // `sqrt(d^2) < collision_range` test, which the resolve re-evaluates exactly.
+#include <stdlib.h>
+
 #include "amc_grid_dev.h"
 
 #define AMC_CR2_INFLATE (1.0 + 1.0e-9)
@@ -93,63 +95,82 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
 // Measured on MI355X (tools/ubench_vmem.hip): random 8..32-byte loads over a >L2 footprint run at ~5.5e10 requests/s
 // whatever their width, index-ordered ones at ~2e11/s — the kernel's cost is its number of random requests
 // (heads + list elements, ~1.3 per particle at 0.25 particles per cell), not its bytes.
-__global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
-                                                      int max_cand, amc_dev_counters *cnt, amc_adj D)
+// One list NODE: its own cell's list (the part inserted before it) and the lists of the lower-numbered cells its box overlaps.
+AMC_DEV void amc_detect_node(const amc_grid &G, const amc_lists &B, int node, double cr2i, double cr_probe, int max_cand,
+                             amc_dev_counters *cnt, const amc_adj &D)
 {
-    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) {
-        const amc_rec me_r = B.rec[p];
-        double3 me;
-        amc_rec_pos(G, me_r, me.x, me.y, me.z);
-        auto found_pair = [&](int q) { amc_push_candidate((int)p, q, max_cand, cnt, D); };
-        // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
-        // every same-cell pair is thereby met exactly once, by the later-inserted particle, and the head is not needed);
-        // slots 1..8: the other cells my box overlaps, but only those with a SMALLER cell id: two particles closer than
-        // collision_range lie in each other's box, so a cross-cell pair is met exactly once, from the larger cell.  The kernel is bound by the LATENCY of dependent loads (head -> record -> next record),
-        // so all cursors advance together: every round issues the loads of all live cursors before using any of them.
-        int q[9];
-        q[0] = amc_rec_next(me_r);
-        {
-            int ocx, ocy, ocz;
-            amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
-            const int c_own = amc_grid_cell(G, ocx, ocy, ocz, nullptr);
-            int c_lo[4], c_hi[4];
-            const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
-            int cell[8];
+    const amc_rec me_r = B.rec[node];
+    if (me_r.x != me_r.x) return;       // a particle's own node after the particle was filed again under an extra node (amc_lists)
+    const int me_p = amc_node_particle(B, node);
+    double3 me;
+    amc_rec_pos(G, me_r, me.x, me.y, me.z);
+    auto found_pair = [&](int q) { amc_push_candidate(me_p, amc_node_particle(B, q), max_cand, cnt, D); };
+    // Nine list cursors per particle — slot 0: my own cell, only the particles inserted BEFORE me (my `next` chain;
+    // every same-cell pair is thereby met exactly once, by the later-inserted particle, and the head is not needed);
+    // slots 1..8: the other cells my box overlaps, but only those with a SMALLER cell id: two particles closer than
+    // collision_range lie in each other's box, so a cross-cell pair is met exactly once, from the larger cell.  The kernel is bound by the LATENCY of dependent loads (head -> record -> next record),
+    // so all cursors advance together: every round issues the loads of all live cursors before using any of them.
+    int q[9];
+    q[0] = amc_rec_next(me_r);
+    {
+        int ocx, ocy, ocz;
+        amc_grid_coords(G, me.x, me.y, me.z, ocx, ocy, ocz);
+        const int c_own = amc_grid_cell(G, ocx, ocy, ocz, nullptr);
+        int c_lo[4], c_hi[4];
+        const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
+        int cell[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const int c = c_lo[k < nc ? k : 0] + t;
-                    cell[2 * k + t] = (k < nc && c <= c_hi[k < nc ? k : 0] && c < c_own) ? c : -1;
-                }
-            unsigned long long hv[8];
+            for (int t = 0; t < 2; t++) {
+                const int c = c_lo[k < nc ? k : 0] + t;
+                cell[2 * k + t] = (k < nc && c <= c_hi[k < nc ? k : 0] && c < c_own) ? c : -1;
+            }
+        unsigned long long hv[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) hv[e] = (cell[e] >= 0) ? B.head[cell[e]] : 0ULL;
+        for (int e = 0; e < 8; e++) hv[e] = (cell[e] >= 0) ? B.head[cell[e]] : 0ULL;
 #pragma unroll
-            for (int e = 0; e < 8; e++)
-                q[1 + e] = (cell[e] >= 0 && (unsigned int)(hv[e] >> 32) == B.epoch) ? (int)(unsigned int)(hv[e] & 0xffffffffULL) : -1;
-        }
-        for (;;) {
-            bool live = false;
-#pragma unroll
-            for (int e = 0; e < 9; e++) live |= q[e] >= 0;
-            if (!live) break;
-            amc_rec o[9];
-#pragma unroll
-            for (int e = 0; e < 9; e++)
-                if (q[e] >= 0) o[e] = B.rec[q[e]];
-#pragma unroll
-            for (int e = 0; e < 9; e++)
-                if (q[e] >= 0) {
-                    double ox, oy, oz;
-                    amc_rec_pos(G, o[e], ox, oy, oz);
-                    const double ex = ox - me.x, ey = oy - me.y, ez = oz - me.z;
-                    if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q[e]);
-                    q[e] = amc_rec_next(o[e]);
-                }
-        }
+        for (int e = 0; e < 8; e++)
+            q[1 + e] = (cell[e] >= 0 && (unsigned int)(hv[e] >> 32) == B.epoch) ? (int)(unsigned int)(hv[e] & 0xffffffffULL) : -1;
     }
+    for (;;) {
+        bool live = false;
+#pragma unroll
+        for (int e = 0; e < 9; e++) live |= q[e] >= 0;
+        if (!live) break;
+        amc_rec o[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++)
+            if (q[e] >= 0) o[e] = B.rec[q[e]];
+#pragma unroll
+        for (int e = 0; e < 9; e++)
+            if (q[e] >= 0) {
+                double ox, oy, oz;
+                amc_rec_pos(G, o[e], ox, oy, oz);
+                const double ex = ox - me.x, ey = oy - me.y, ez = oz - me.z;
+                if (ex * ex + ey * ey + ez * ez < cr2i) found_pair(q[e]);      // (false for a record with a NaN position)
+                q[e] = amc_rec_next(o[e]);
+            }
+    }
+}
+
+// One thread per particle; in an overlapped run (amc_stream.hip) a few more blocks take the extra nodes (amc_lists), whose
+// number only the device knows.
+__global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
+                                                      int max_cand, amc_dev_counters *cnt, amc_adj D, const int *extra_count,
+                                                      int max_extra)
+{
+    const long long nb = (n + blockDim.x - 1) / blockDim.x;
+    if ((long long)blockIdx.x < nb) {
+        const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (p < n) amc_detect_node(G, B, (int)p, cr2i, cr_probe, max_cand, cnt, D);
+        return;
+    }
+    int ne = *extra_count;
+    if (ne > max_extra) ne = max_extra;
+    const int stride = (int)((gridDim.x - nb) * blockDim.x);
+    for (int e = (int)((blockIdx.x - nb) * blockDim.x + threadIdx.x); e < ne; e += stride)
+        amc_detect_node(G, B, (int)n + e, cr2i, cr_probe, max_cand, cnt, D);
 }
 
 // ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
@@ -298,8 +319,13 @@ hipError_t amc_launch_detect(amc_ctx *c)
                                    c->S.z, (int)n, ntiles, cr2i, c->W.max_cand, c->d_cnt, D);
         }
     } else {
-        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), c->G, c->B, n, cr2i,
-                           c->G.cr_probe, c->W.max_cand, c->d_cnt, D);
+        // (an overlapped run: four more blocks for the particles the fix-up kernel filed again under extra nodes)
+        const bool extras = c->B.extra != nullptr;
+        const int slot = (c->B.extra == c->extra_buf[1]) ? 1 : 0;
+        static const int bs = getenv("AMC_DETECT_BS") ? atoi(getenv("AMC_DETECT_BS")) : 256;      // (experiments: 64 / 128 / 256)
+        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + bs - 1) / bs) + (extras ? 4u : 0u)), dim3(bs), c->G, c->B, n, cr2i,
+                   c->G.cr_probe, c->W.max_cand, c->d_cnt, D, (const int *)(extras ? c->extra_count + slot : nullptr),
+                   c->max_extra);
     }
     amc_prof_end(c);
     return hipGetLastError();

@@ -91,6 +91,8 @@ AMC_DEV int amc_grid_box_cell(const amc_grid &G, double x, double y, double z, d
 
 // ---- per-cell lists -----------------------------------------------------------------------------------------------------
 AMC_DEV int amc_rec_next(const amc_rec &r) { return r.next; }
+// the particle a list node stands for (amc_lists: nodes below n are the particles themselves)
+AMC_DEV int amc_node_particle(const amc_lists &B, int node) { return node < B.n ? node : B.extra[node - B.n]; }
 // position of a list record (absolute, double): what the particle was filed under, within the rounding of a float
 AMC_DEV void amc_rec_pos(const amc_grid &G, const amc_rec &r, double &x, double &y, double &z)
 {

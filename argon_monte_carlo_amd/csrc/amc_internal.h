@@ -48,8 +48,22 @@ struct amc_rec {
 };
 struct amc_lists {
     unsigned long long *head; // [ncells]
-    amc_rec *rec;             // [n]
+    amc_rec *rec;             // [n + max_extra]: list NODES.  Node p < n is particle p.  Nodes n + e are handed out by the fix-up
+                              // kernel of an overlapped run (amc_stream.hip) to particles that had been filed under a
+                              // speculative position: their own node stays linked with a position no test passes (NaN) and
+                              // the particle is filed again under node n + e, extra[e] = particle
     unsigned int epoch;       // current binning epoch (>= 1)
+    int n;                    // particles (nodes below n are particles themselves)
+    const int *extra;         // [max_extra] node n + e -> particle (nullptr outside an overlapped run: no such node exists)
+};
+#define AMC_EXTRA_NODES(n) ((int)std::min<long long>(std::max<long long>(4096, (long long)(n) / 64), 1 << 22))
+
+// What the streaming pass of an OVERLAPPED run needs beyond the plain one (amc_run): it reads the state the
+// running sweep reads (S) and writes the other buffer (S_out), leaves out every particle the sweep's detect kernel linked
+// into a candidate (graph head tagged with the sweep's epoch) and defers its events (amc_out::wev).
+struct amc_ovl {
+    const unsigned long long *adj_head;   // nullptr: plain pass
+    unsigned int skip_epoch;              // epoch of the sweep in flight (0: none)
 };
 
 // results of the last sweep that have not been written to the particle arrays yet: the next streaming pass picks them
@@ -87,6 +101,8 @@ struct amc_resolve_ws {
     int max_cand;
     unsigned long long *adj_head;   // [n] (sweep epoch << 32) | last candidate pushed that touches the particle
     int *slot_of;             // [n] particle -> slot or -1
+    unsigned int *victim;     // [n] == sweep epoch: the sweep pulled the particle into a cluster AFTER its detect kernel (it is in
+                              // no candidate, so the streaming pass of an overlapped run has advanced it speculatively)
     int max_slots;
     int4 *sl_meta;            // [max_slots] (particle, cluster label at the wide kernel's hand-over, round of the last emulation, -)
     int *sl_hits;             // collisions (low half) and failed contact solves (high half) counted on the slot: atomics only
@@ -152,11 +168,25 @@ struct amc_ctx {
     int64_t n, lo, hi;
     bool uploaded;
     bool keep_prior;
-    amc_state S;
+    amc_state S;              // the CURRENT state arrays (one of S_buf's two sets)
+    amc_state S_buf[2];       // [1] is allocated by the first overlapped run: its streaming pass writes the buffer the sweep in
+    char *s_slab2;            // flight does not read
     amc_grid G;
     std::vector<int> h_lay_lo, h_lay_n, h_lay_off;
     int *d_lay;               // device copy of the three layer tables, contiguous
-    amc_lists B;
+    amc_lists B;              // the CURRENT per-cell lists (one of B_buf's two)
+    amc_lists B_buf[2];
+    int *extra_buf[2];        // node -> particle of the extra nodes of each list buffer, and how many were handed out
+    int *extra_count;         // [2]
+    int max_extra;
+    amc_wev wev_buf[2];       // deferred events of the overlapped streaming pass, by step parity
+    hipStream_t stream2;      // the overlapped streaming pass runs here
+    hipEvent_t ev_detect, ev_stream;
+    unsigned int *ovl_flags;  // two words (64 bytes apart) the streams of an overlapped run signal each other through
+    unsigned int ovl_tick;    // (hipStreamWriteValue32 / hipStreamWaitValue32: a dependency costs ~2 us instead of the ~8 us of an
+    int ovl_sync_values;      // event record + wait pair, tools/ubench_xstream.hip; AMC_OVERLAP_SYNC=event selects the events)
+    int64_t ovl_steps;        // steps run overlapped so far
+    int overlap_mode;         // AMC_OVERLAP: 1 (default) two streams, 2 the same kernels in order on one stream (debug), 0 off
     amc_resolve_ws W;
     char *w_slab;             // the one allocation W's arrays are carved from
     char *s_slab;             // the one allocation the particle state arrays are carved from
@@ -221,6 +251,8 @@ int amc_fail(amc_ctx *c, int code, const char *fmt, ...);
 // line add up to more than the step).  Outside a bracket both events are null: a plain launch.
 #define AMC_LAUNCH(c, kernel, grid, block, ...) \
     hipExtLaunchKernelGGL(kernel, grid, block, 0, (c)->stream, (c)->prof_ev0, (c)->prof_ev1, 0, __VA_ARGS__)
+#define AMC_LAUNCH_ON(c, stream_, kernel, grid, block, ...) \
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, stream_, (c)->prof_ev0, (c)->prof_ev1, 0, __VA_ARGS__)
 
 // profiling brackets
 void amc_prof_begin(amc_ctx *c, int kclass);
@@ -231,6 +263,7 @@ void amc_prof_collect(amc_ctx *c);
 // stage bits of the streaming kernel
 #define AMC_PLAN_SMALL 430      // default of amc_ctx::plan_small: measured crossover of the two launch plans (tools/plan_sweep.sh;
                                 // experiments: environment variable AMC_PLAN_SMALL)
+#define AMC_OVERLAP_MIN_N 300000 // default of the overlapped run (amc_api.hip): particles from which amc_run overlaps
 #define AMC_ST_DRIFT 1
 #define AMC_ST_WALLS 2
 #define AMC_ST_BOUNDS 4
@@ -238,6 +271,10 @@ void amc_prof_collect(amc_ctx *c);
 
 // launchers (each enqueues on c->stream; returns hipError_t of the launch)
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin = false);
+// the overlapped run (amc_stream.hip): the streaming pass of the next step while the sweep is being resolved,
+// and the fix-up kernel that joins the two
+hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, unsigned int skip_epoch, hipStream_t stream);
+hipError_t amc_launch_fixup(amc_ctx *c, double dt, int stages, int from, unsigned int sweep_epoch);
 hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build over all n particles (stages, multi-GPU)
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit

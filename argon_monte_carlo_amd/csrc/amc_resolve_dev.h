@@ -816,7 +816,8 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
             o0[k] = W.hist[h2]; on0[k] = W.ov_next[h2];
         }
     }
-    auto grid_entry = [&](int idx, const amc_rec &r) {
+    auto grid_entry = [&](int node, const amc_rec &r) {
+        const int idx = amc_node_particle(A.B, node);
         if (idx == pme) return;
         double rx, ry, rz;
         amc_rec_pos(G, r, rx, ry, rz);
@@ -824,7 +825,7 @@ AMC_DEV void rs_probe(const rs_args &A, const amc_grid &G, rs_shared *cnt, const
         if (ax * ax + ay * ay + az * az < cr2g) {
             const int so = W.slot_of[idx];
             if (so >= 0 && so < ns && label[so] == lme) return;
-            if (so < 0) rs_claim_slot(W, cnt, cap, idx);
+            if (so < 0) { rs_claim_slot(W, cnt, cap, idx); W.victim[idx] = A.sweep_epoch; }    // (a particle in no candidate)
             rs_add_edge(W, cnt, pme, idx);
         }
     };

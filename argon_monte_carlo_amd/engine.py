@@ -156,6 +156,12 @@ class Engine:
     def synchronize(self):
         self._ck(self.lib.amc_synchronize(self._ctx))
 
+    def overlap_stats(self):
+        """(steps amc_run has overlapped, particles advanced again after a sweep pulled them in, mode, extra list nodes)."""
+        out = np.zeros(4, dtype=np.int64)
+        self._ck(self.lib.amc_overlap_stats(self._ctx, out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return dict(steps=int(out[0]), refiled=int(out[1]), mode=int(out[2]), extra_nodes=int(out[3]))
+
     def profile(self, on=True):
         self._ck(self.lib.amc_profile(self._ctx, int(on)))
 

@@ -33,8 +33,9 @@ ALGO_BYTES = {"drift_walls": 137, "detect": 24, "bin_count": 24, "bounds": 24}
 KERNEL_OF_CLASS = {"drift_walls": "k_stream", "bin_count": "k_bin_lists / k_kin_pack / k_kin_unpack (list build)",
                    "detect": "k_detect_lists", "resolve": "k_resolve<GEOM,0> (ordered workgroup)",
                    "bounds": "k_stream (bounds-only pass)", "clusters_wide": "k_clusters_wide",
-                   "commit": "k_commit", "allgather": "all-gather (RCCL)"}
-SWEEP_CLASSES = ("bin_count", "detect", "clusters_wide", "resolve", "commit")     # the p-p pair sweep (24 B per particle)
+                   "commit": "k_commit", "fixup": "k_fixup (overlapped run: sweep results -> next state, sweep commit)",
+                   "allgather": "all-gather (RCCL)"}
+SWEEP_CLASSES = ("bin_count", "detect", "clusters_wide", "resolve", "commit", "fixup")     # the p-p pair sweep (24 B per particle)
 
 WORKLOADS = {
     "cube_1e5": ("cube", 100_000),

@@ -333,10 +333,18 @@ int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no ho
 #define AMC_K_RESOLVE_MORE 8     /* reserved (later rounds run inside k_resolve)                                */
 #define AMC_K_COMMIT 9           /* k_commit: a sweep's commit as a launch of its own (else it rides along with the next k_stream) */
 #define AMC_K_CLUSTERS_WIDE 10   /* k_clusters_wide: every small cluster emulated and validated wide, before the ordered workgroup */
+#define AMC_K_FIXUP 11           /* k_fixup: joins an overlapped run's early streaming pass with the sweep's results (below) */
 #define AMC_K_COUNT 12
 int amc_profile(amc_ctx *ctx, int enable);
 int amc_kernel_times(amc_ctx *ctx, double *total_ms /*[AMC_K_COUNT]*/, int64_t *launches /*[AMC_K_COUNT]*/);
 const char *amc_kernel_name(int k);
+/* amc_run overlaps the streaming pass of step s + 1 with the resolve of sweep s (whole range in one context, cube /
+ * specular pore, binned detector, at least two steps; environment AMC_OVERLAP=0 turns it off, =2 runs the same kernels in
+ * order on one stream).  Results are those of the plain sequence bit for bit — the loop body of Pore:416-557 / Cube:175-338
+ * once per step.  out[0] = steps run that way so far, out[1] = particles a sweep pulled into a cluster after the next pass
+ * had already advanced them (advanced again from the sweep's result and filed under an extra list node), out[2] = mode,
+ * out[3] = extra list nodes available per step. */
+int amc_overlap_stats(amc_ctx *ctx, int64_t *out /*[4]*/);
 
 #ifdef __cplusplus
 }

@@ -1028,3 +1028,82 @@ def test_device_initial_conditions_pore(Engine):
     st = eng.run(c["dt"], 3)
     assert st["flags"] == 0 and st["n_pp"] > 0 and st["n_wall"] > 0
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------- the overlapped run
+@pytest.mark.parametrize("mode", ["2", "1"])
+@pytest.mark.parametrize("name,kind", [("step_cube_dense.npz", "cube"), ("step_cube_a.npz", "cube"), ("step_pore_a.npz", "pore")])
+def test_overlapped_run_equals_the_oracle_on_the_reference_runs(Engine, O, golden_dir, monkeypatch, name, kind, mode):
+    """amc_run overlaps the streaming pass of step s + 1 with the resolve of sweep s.  From the reference's
+    initial states — the dense cube among them, where sweeps pull uninvolved particles into clusters in most steps, i.e.
+    particles the early pass has already advanced are advanced again from the sweep's result and filed under extra list
+    nodes — the state after run(k) equals the oracle's bit for bit, so do counters, histograms and the completed paths.
+    mode 2 = the same kernels in order on one stream, mode 1 = on two streams."""
+    Gs = load_step(golden_dir, name)
+    sigma = 3.6 * 10**(-19) * float(Gs["meta_sigma_mult"])
+    K = int(Gs["meta_K"])
+    p, c = (PR.cube_params(n=K, sigma=sigma) if kind == "cube" else PR.pore_params(n=K, sigma=sigma))
+    dt = float(Gs["dt"])
+    p.detect_mode = 1                           # (the binned detector also below 4,096 particles: the overlapped run needs the grid)
+    init = [Gs[f"s-001_{k}"] for k in STATE_KEYS]
+    monkeypatch.setenv("AMC_OVERLAP", mode)
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul")
+    eng.upload(*init[:10], init[10])
+    orc.upload(*init[:10], flag=init[10])
+    tot = {}
+    refiled = 0
+    for chunk in (7, 2, 16):                    # odd and even numbers of steps: either state buffer ends up current
+        st = eng.run(dt, chunk)
+        so = {}
+        for _ in range(chunk):
+            rc, s1 = orc.timestep(dt)
+            assert rc == 0
+            for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths"):
+                so[k] = so.get(k, 0) + s1[k]
+        for k in so:
+            assert st[k] == so[k], (chunk, k, st, so)
+        assert_state_equal(eng.download(), orc.state(), (name, mode, chunk))
+    ov = eng.overlap_stats()
+    assert ov["steps"] == 25 and ov["mode"] == int(mode)
+    if name == "step_cube_dense.npz":
+        assert ov["refiled"] > 0, ov          # the case the extra list nodes exist for did occur
+    rec = eng.drain_paths()
+    ref = orc.paths()
+    got = paths_of(rec)
+    exp = np.stack([ref["total"], ref["px"], ref["py"], ref["pz"]], axis=1) if len(ref["total"]) else np.zeros((0, 4))
+    assert got.shape == exp.shape
+    assert np.array_equal(got[np.lexsort(got.T[::-1])], exp[np.lexsort(exp.T[::-1])])
+    eng.close()
+
+
+@pytest.mark.parametrize("workload,n,steps", [("cube", 100_000, 120), ("pore", 300_000, 60)])
+def test_overlapped_run_equals_the_plain_sequence_at_size(Engine, O, monkeypatch, workload, n, steps):
+    """The same at BASELINE-like sizes against BOTH the plain sequence (AMC_OVERLAP=0) and the oracle: state, counters and
+    device histograms."""
+    if workload == "cube":
+        p, c = PR.cube_params_for_n(n)
+        init = IC.cube_ic(p, c, seed=127)
+    else:
+        p, c = PR.pore_params(n=n)
+        init = IC.pore_ic(p, c, seed=17)
+    p.reserved1 = 1
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("AMC_OVERLAP", mode)
+        eng = Engine(p)
+        eng.upload(*init)
+        st = eng.run(c["dt"], steps)
+        res[mode] = (st, eng.download(), eng.histograms(), eng.overlap_stats())
+        eng.close()
+    assert res["0"][3]["steps"] == 0 and res["1"][3]["steps"] == steps
+    for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_candidates"):
+        assert res["0"][0][k] == res["1"][0][k], (k, res["0"][0], res["1"][0])
+    assert_state_equal(res["1"][1], res["0"][1], workload)
+    assert np.array_equal(res["0"][2][0], res["1"][2][0]) and res["0"][2][1] == res["1"][2][1]
+    orc = O.Oracle(p, mode="mul")
+    orc.upload(*init)
+    for _ in range(steps):
+        rc, _ = orc.timestep(c["dt"])
+        assert rc == 0
+    assert_state_equal(res["1"][1], orc.state(), workload + " vs oracle")
