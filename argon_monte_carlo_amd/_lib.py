@@ -60,6 +60,9 @@ SIGNATURES = {
     "amc_mg_exchange_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "amc_mg_pack": (C.c_int, [_ctx, C.c_int]),
     "amc_mg_sweep": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "amc_mg_candidates_view": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "amc_mg_detect": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "amc_mg_resolve": (C.c_int, [_ctx, C.c_int]),
     "amc_mg_bounds": (C.c_int, [_ctx]),
     "amc_mg_finish": (C.c_int, [_ctx, C.POINTER(AmcStepStats)]),
     "amc_profile": (C.c_int, [_ctx, C.c_int]),

@@ -181,6 +181,8 @@ void amc_destroy(amc_ctx *c)
     if (c->T.count) hipFree(c->T.count);
     { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
       for (void *q : td) if (q) hipFree(q); }
+    if (c->cand_send) hipFree(c->cand_send);
+    if (c->cand_recv) hipFree(c->cand_recv);
     if (c->kin_send) hipFree(c->kin_send);
     if (c->kin_recv) hipFree(c->kin_recv);
     if (c->kin_vpub) hipFree(c->kin_vpub);
@@ -246,6 +248,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->d_cnt = nullptr; c->own_stream = nullptr; c->h_pin = nullptr; c->h_pin_bytes = 0; c->plan_split = false;
     c->plan_small = AMC_PLAN_SMALL;
     if (const char *e = getenv("AMC_PLAN_SMALL")) { const int v = atoi(e); if (v >= 0) c->plan_small = v; }
+    c->cand_send = c->cand_recv = nullptr; c->cand_cap = 0; c->cand_world = 0;
     c->kin_send = c->kin_recv = c->kin_vpub = nullptr; c->kin_world = 0; c->kin_m = c->kin_cap = c->kin_block = 0; c->kin_lists = false; c->kin_counts_clear = false;
     c->TD.idx = nullptr; c->TD.count = nullptr; c->TD.t = c->TD.contact = c->TD.normal = c->TD.dir = c->TD.Es = c->TD.dpz = c->TD.dE = nullptr;
     c->TD.ok = nullptr; c->TD.cap = 0; c->TD.fetched = false;

@@ -92,6 +92,61 @@ int amc_mg_sweep(amc_ctx *c, int world, int rank)
     return amc_enqueue_sweep(c, lists, true);
 }
 
+// ---- detection sharded by index: unpack + detect over [lo, hi) | second all-gather (candidate pairs) | graph + resolve ----
+int amc_mg_candidates_view(amc_ctx *c, int world, void **send, void **recv, int64_t *block_ints)
+{
+    if (!c || world < 1 || !send || !recv || !block_ints) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    if (c->cand_world != world) {
+        AMC_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->cand_send) hipFree(c->cand_send);
+        if (c->cand_recv) hipFree(c->cand_recv);
+        c->cand_send = c->cand_recv = nullptr;
+        // a quarter of the context's candidate capacity (n / 32 pairs by default; amc_params.max_candidates scales it): ~60x the
+        // pairs a rank of eight finds per step at the reference's density, and room for the first step of a synthetic start,
+        // whose uniformly placed particles overlap by the ten thousand
+        long long cap = std::max<long long>(4096, c->W.max_cand / 4);
+        if (const char *e = getenv("AMC_MG_CANDIDATES")) { const long long v = atoll(e); if (v > 0) cap = v; }      // (tests)
+        c->cand_cap = (int)std::min<long long>(cap, c->W.max_cand);
+        const size_t blk = (size_t)2 + 2 * (size_t)c->cand_cap;
+        AMC_HIP(c, dalloc(&c->cand_send, blk));
+        AMC_HIP(c, dalloc(&c->cand_recv, blk * (size_t)world));
+        AMC_HIP(c, hipMemsetAsync(c->cand_send, 0, sizeof(int) * blk, c->stream));
+        AMC_HIP(c, hipMemsetAsync(c->cand_recv, 0, sizeof(int) * blk * (size_t)world, c->stream));
+        AMC_HIP(c, hipStreamSynchronize(c->stream));
+        c->cand_world = world;
+    }
+    *send = c->cand_send; *recv = c->cand_recv; *block_ints = 2 + 2 * (int64_t)c->cand_cap;
+    return AMC_OK;
+}
+
+int amc_mg_detect(amc_ctx *c, int world, int rank)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (c->allpairs || c->detect_ap || c->P.geometry == AMC_GEOM_CELL) return amc_fail(c, AMC_ERR_INVALID, "multi-GPU needs the binned detector");
+    if (world != c->cand_world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_candidates_view(world=%d) has not been called", world);
+    AMC_HIP(c, hipSetDevice(c->device));
+    { int rc_ = amc_flush(c); if (rc_) return rc_; }
+    int rc = mg_check_shard(c, world, rank);
+    if (rc) return rc;
+    if (!c->kin_lists) return amc_fail(c, AMC_ERR_STATE, "amc_mg_detect(world=%d) without amc_mg_pack in this step", world);
+    if (world > 1) AMC_HIP(c, amc_launch_kin_pack(c, world, rank, 1));          // the other shards' positions in, lists completed
+    c->kin_lists = false;
+    AMC_HIP(c, amc_launch_detect_own(c));
+    return AMC_OK;
+}
+
+int amc_mg_resolve(amc_ctx *c, int world)
+{
+    if (!c || !c->uploaded) return AMC_ERR_STATE;
+    if (world != c->cand_world) return amc_fail(c, AMC_ERR_STATE, "amc_mg_candidates_view(world=%d) has not been called", world);
+    AMC_HIP(c, hipSetDevice(c->device));
+    AMC_HIP(c, amc_launch_ingest(c, world));
+    AMC_HIP(c, amc_launch_resolve(c, true));
+    c->lazy_pending = true;
+    return AMC_OK;
+}
+
 int amc_mg_bounds(amc_ctx *c)
 {
     if (!c || !c->uploaded) return AMC_ERR_STATE;

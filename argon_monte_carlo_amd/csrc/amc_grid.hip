@@ -173,6 +173,74 @@ __global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, l
         amc_detect_node(G, B, (int)n + e, cr2i, cr_probe, max_cand, cnt, D);
 }
 
+// ---- detection sharded by index (multi-GPU) ------------------------------------------------------------------
+// A rank examines only ITS particles, but against everybody: particle p walks the WHOLE list of every cell its box
+// overlaps, its own cell included, and keeps the pairs whose partner has the lower index — so a pair is found exactly once
+// in the whole job, by the rank that owns its higher index.  The pairs go into the rank's block of a second, small
+// all-gather ([0] = count, then (i, j) as two 32-bit integers each); k_ingest_candidates then builds the candidate graph
+// from the blocks of all ranks, identically everywhere, and the (replicated) resolve proceeds as on one GPU.
+__global__ __launch_bounds__(256) void k_detect_own(amc_grid G, amc_lists B, long long lo, long long hi, double cr2i,
+                                                    double cr_probe, int *__restrict__ out, int cap, amc_dev_counters *cnt)
+{
+    const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hi) return;
+    const amc_rec me_r = B.rec[p];
+    double3 me;
+    amc_rec_pos(G, me_r, me.x, me.y, me.z);
+    int c_lo[4], c_hi[4];
+    const int nc = amc_grid_box_ranges(G, me.x, me.y, me.z, cr_probe, c_lo, c_hi);
+    int q[8];
+    unsigned long long hv[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int c = c_lo[k < nc ? k : 0] + t;
+            const bool on = k < nc && c <= c_hi[k < nc ? k : 0];
+            hv[2 * k + t] = on ? B.head[c] : 0ULL;
+            q[2 * k + t] = on ? 0 : -1;
+        }
+#pragma unroll
+    for (int e = 0; e < 8; e++)
+        q[e] = (q[e] == 0 && (unsigned int)(hv[e] >> 32) == B.epoch) ? (int)(unsigned int)(hv[e] & 0xffffffffULL) : -1;
+    for (;;) {
+        bool live = false;
+#pragma unroll
+        for (int e = 0; e < 8; e++) live |= q[e] >= 0;
+        if (!live) break;
+        amc_rec o[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (q[e] >= 0) o[e] = B.rec[q[e]];
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+            if (q[e] >= 0) {
+                double ox, oy, oz;
+                amc_rec_pos(G, o[e], ox, oy, oz);
+                const double ex = ox - me.x, ey = oy - me.y, ez = oz - me.z;
+                if (q[e] < (int)p && ex * ex + ey * ey + ez * ez < cr2i) {
+                    const int k = atomicAdd(&out[0], 1);
+                    if (k < cap) { out[2 + 2 * k] = (int)p; out[3 + 2 * k] = q[e]; }
+                    else atomicOr(&cnt->flags, 1ULL);       // (candidate overflow: the step reports AMC_ERR_CAPACITY)
+                }
+                q[e] = amc_rec_next(o[e]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ingest_candidates(const int *__restrict__ blocks, int world, int block_ints, int cap,
+                                                           int max_cand, amc_dev_counters *cnt, amc_adj D, int *__restrict__ own)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gstride = gridDim.x * blockDim.x;
+    for (int r = 0; r < world; r++) {
+        const int *b = blocks + (size_t)r * block_ints;
+        int nr = b[0];
+        if (nr > cap) nr = cap;
+        for (int k = gtid; k < nr; k += gstride) amc_push_candidate(b[2 + 2 * k], b[3 + 2 * k], max_cand, cnt, D);
+    }
+    if (gtid == 0) own[0] = 0;          // (this rank's block has been gathered: its counter is cleared for the next step)
+}
+
 // ---- all-pairs detection: LDS tile of 256 j-particles against 256 i-particles in registers ---------------------------
 #define AP_T 256
 __global__ __launch_bounds__(AP_T) void k_detect_allpairs(const double *__restrict__ x, const double *__restrict__ y,
@@ -327,6 +395,33 @@ hipError_t amc_launch_detect(amc_ctx *c)
                    c->G.cr_probe, c->W.max_cand, c->d_cnt, D, (const int *)(extras ? c->extra_count + slot : nullptr),
                    c->max_extra);
     }
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+
+// multi-GPU: detection over [lo, hi) into this rank's candidate block, and the candidate graph from all blocks
+hipError_t amc_launch_detect_own(amc_ctx *c)
+{
+    const long long cnt = c->hi - c->lo;
+    amc_prof_begin(c, AMC_K_DETECT);
+    if (cnt > 0)
+        AMC_LAUNCH(c, k_detect_own, dim3((unsigned)((cnt + 255) / 256)), dim3(256), c->G, c->B, (long long)c->lo, (long long)c->hi,
+                   c->G.cr2_probe, c->G.cr_probe, c->cand_send, c->cand_cap, c->d_cnt);
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+
+hipError_t amc_launch_ingest(amc_ctx *c, int world)
+{
+    amc_adj D;
+    c->sweep_epoch = (c->sweep_epoch + 1u) & 0x3fffffffu;
+    if (c->sweep_epoch == 0u) c->sweep_epoch = 1u;
+    c->plan_split = !(c->h_host_ncand && *c->h_host_ncand <= c->plan_small);
+    D.head = c->W.adj_head; D.rec = c->W.cand4; D.sd = c->W.cand_s; D.epoch = c->sweep_epoch;
+    D.sl_meta = c->W.sl_meta; D.sl_hits = c->W.sl_hits; D.ev_gen = c->W.ev_gen; D.mark = c->W.cand_mark;
+    amc_prof_begin(c, AMC_K_DETECT);
+    AMC_LAUNCH(c, k_ingest_candidates, dim3(16), dim3(256), (const int *)c->cand_recv, world, 2 + 2 * c->cand_cap, c->cand_cap,
+               c->W.max_cand, c->d_cnt, D, c->cand_send);
     amc_prof_end(c);
     return hipGetLastError();
 }

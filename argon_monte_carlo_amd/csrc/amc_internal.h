@@ -231,6 +231,8 @@ struct amc_ctx {
                                    // every upload publishes: all ranks upload the same full state)
     int kin_world;
     int64_t kin_m, kin_cap, kin_block;   // shard length (padded), capacity of the velocity-change list (all banks), 3m + banks + 4cap
+    int *cand_send, *cand_recv;    // multi-GPU, detection sharded by index: this rank's candidate block ([0] count, [2 + 2k] pairs)
+    int cand_cap, cand_world;      // and the blocks of all ranks (the second all-gather of a step); pairs per block
     bool kin_lists;                // amc_mg_pack started this step's per-cell lists (the unpack completes them)
     bool kin_counts_clear;         // the bank counters in kin_send are zero (cleared by the last unpack kernel)
 };
@@ -277,6 +279,8 @@ hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, un
 hipError_t amc_launch_fixup(amc_ctx *c, double dt, int stages, int from, unsigned int sweep_epoch);
 hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build over all n particles (stages, multi-GPU)
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
+hipError_t amc_launch_detect_own(amc_ctx *c);          // multi-GPU: own index range against everybody, into the candidate block
+hipError_t amc_launch_ingest(amc_ctx *c, int world);   // ... and the candidate graph from the gathered blocks of all ranks
 hipError_t amc_launch_resolve(amc_ctx *c, bool defer_commit = false);   // resolve_A -> validate -> resolve_B -> commit
 hipError_t amc_launch_apply(amc_ctx *c);                // write deferred sweep results to the particle arrays now
 hipError_t amc_launch_commit(amc_ctx *c);               // the pending commit as a kernel of its own

@@ -1,8 +1,12 @@
 """Multi-GPU driver: one process per GPU, particles sharded by contiguous index range.
 
 Per step every rank advances only its shard (drift + walls + bounds), then ONE all-gather over RCCL/xGMI hands the
-positions of every shard and the velocities that changed to everybody (~28 B per particle), and every rank runs the p-p sweep of the whole
-system exactly as a single GPU would (bin, detect, ordered resolve, commit).  All ranks compute every collision from
+positions of every shard and the velocities that changed to everybody (~28 B per particle).  Detection is sharded by
+index: a rank examines its own particles against everybody and keeps the pairs whose partner has the lower index (every
+close pair is found once, by the owner of its higher index); a second, small all-gather hands the pairs of all ranks to
+everybody, and every rank then resolves the whole system's candidates as a single GPU would (ordered resolve, commit).
+(``replicated_detect=True`` or AMC_MG_REPLICATED=1: the round-2 form, detection of the whole system on every rank, one
+collective per step.)  All ranks compute every collision from
 identical inputs, so cross-shard pairs and chains need no locking, no ownership logic inside the kernels and no further
 exchange: the path accumulators and the flag of a particle only feed its own bookkeeping and are meaningful on its owner
 alone, which is also the rank that emits the particle's completed paths.  Nothing in the step waits for the host.
@@ -90,9 +94,13 @@ class TorchComm:
 class ShardedSimulation:
     SUM_KEYS = ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors")
 
-    def __init__(self, params, rank, world, backend="nccl", stream_ptr=None, engine=None, comm=None):
+    def __init__(self, params, rank, world, backend="nccl", stream_ptr=None, engine=None, comm=None, replicated_detect=None):
+        import os
         self.params, self.rank, self.world = params, int(rank), int(world)
         self.n = int(params.n)
+        if replicated_detect is None:
+            replicated_detect = os.environ.get("AMC_MG_REPLICATED") == "1"
+        self.replicated_detect = bool(replicated_detect)
         self.lo, self.hi = shard_range(self.n, rank, world)
         if engine is None:
             from .engine import ShardEngine
@@ -136,7 +144,21 @@ class ShardedSimulation:
                 self.comm.allgather_packed(send, recv)
                 b.record()
                 self._comm_events.append((a, b))
-        e.mg_sweep(self.world, self.rank)
+        if self.replicated_detect or (self.world == 1 and self.comm.shortcut) or not hasattr(e, "mg_detect"):
+            e.mg_sweep(self.world, self.rank)
+        else:
+            csend, crecv = e.candidate_buffers(self.world)
+            e.mg_detect(self.world, self.rank)              # the other shards in, then my particles against everybody
+            if self._comm_events is None:
+                self.comm.allgather_packed(csend, crecv)    # everybody's candidate pairs to everybody
+            else:
+                import torch
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.comm.allgather_packed(csend, crecv)
+                b.record()
+                self._comm_events.append((a, b))
+            e.mg_resolve(self.world)                        # the same candidate graph and ordered resolve on every rank
         st = e.mg_finish(want_stats)
         if st is None:
             return None

@@ -211,6 +211,22 @@ class ShardEngine(Engine):
     def mg_sweep(self, world, rank):
         self._ck(self.lib.amc_mg_sweep(self._ctx, int(world), int(rank)))
 
+    def candidate_buffers(self, world):
+        """(send, recv) tensors of the step's SECOND all-gather (detection sharded by index): this rank's candidate pairs
+        (int32[block]: count, -, then (i, j) pairs) and the blocks of all ranks."""
+        if getattr(self, "_cb_world", None) != world:
+            send, recv, blk = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+            self._ck(self.lib.amc_mg_candidates_view(self._ctx, int(world), C.byref(send), C.byref(recv), C.byref(blk)))
+            self._cb = (self._wrap(send.value, blk.value, "<i4"), self._wrap(recv.value, blk.value * world, "<i4"))
+            self._cb_world = world
+        return self._cb
+
+    def mg_detect(self, world, rank):
+        self._ck(self.lib.amc_mg_detect(self._ctx, int(world), int(rank)))
+
+    def mg_resolve(self, world):
+        self._ck(self.lib.amc_mg_resolve(self._ctx, int(world)))
+
     def mg_finish(self, want_stats=True):
         if not want_stats:
             self._ck(self.lib.amc_mg_finish(self._ctx, None))

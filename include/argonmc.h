@@ -317,6 +317,17 @@ int amc_mg_local(amc_ctx *ctx, double dt);
 int amc_mg_exchange_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *block);
 int amc_mg_pack(amc_ctx *ctx, int world);
 int amc_mg_sweep(amc_ctx *ctx, int world, int rank);       /* world == 1: no unpack (nothing was exchanged) */
+/* Detection sharded by index (the default of the driver for world > 1; amc_mg_sweep above is the replicated form): a rank
+ * examines only the particles of [lo,hi), but against everybody, and keeps the pairs whose partner has the lower index —
+ * every close pair of the system is found exactly once, by the owner of its higher index (the i > j rule of Pore:168-169
+ * across shards).  Its pairs travel in a second, small all-gather: *block_ints 32-bit integers per rank, [0] = number of
+ * pairs, [2 + 2k], [3 + 2k] = (i, j); room for max(4096, max_candidates / 4) pairs, overflow sets flag bit 0 (AMC_ERR_CAPACITY).
+ *   amc_mg_pack -> all-gather #1 -> amc_mg_detect (unpack + detect) -> all-gather #2 -> amc_mg_resolve -> amc_mg_finish
+ * amc_mg_resolve builds the candidate graph from the blocks of all ranks — the same on every rank — and runs the ordered
+ * resolve of the whole system (replicated: it needs every member of a cluster, wherever it lives). */
+int amc_mg_candidates_view(amc_ctx *ctx, int world, void **send, void **recv, int64_t *block_ints);
+int amc_mg_detect(amc_ctx *ctx, int world, int rank);
+int amc_mg_resolve(amc_ctx *ctx, int world);
 int amc_mg_bounds(amc_ctx *ctx);
 int amc_mg_finish(amc_ctx *ctx, amc_step_stats *out);      /* out == NULL: no host synchronisation (counters stay on the device) */
 

@@ -61,7 +61,13 @@ class NumpyShardEngine:
         for e, k in enumerate(KEYS[:6]):
             t[e, :self.hi - self.lo] = self.a[k][self.lo:self.hi]
 
-    def mg_sweep(self, world, rank):
+    def candidate_buffers(self, world):
+        self.ccap = 4 * self.n
+        self.csend = np.zeros(2 + 2 * self.ccap, dtype=np.int32)
+        self.crecv = np.zeros(world * (2 + 2 * self.ccap), dtype=np.int32)
+        return torch.from_numpy(self.csend), torch.from_numpy(self.crecv)
+
+    def _unpack(self, world, rank):
         if world > 1:
             for r in range(world):
                 lo, hi = shard_range(self.n, r, world)
@@ -71,10 +77,42 @@ class NumpyShardEngine:
                 blk = self.recv[r * 6 * self.m:(r + 1) * 6 * self.m].reshape(6, self.m)
                 for e, k in enumerate(KEYS[:6]):
                     self.a[k][lo:hi] = blk[e, :hi - lo]
+
+    def mg_detect(self, world, rank):
+        """detection sharded by index: my particles against everybody, pairs with the lower-indexed partner kept"""
+        self._unpack(world, rank)
+        P = np.stack([self.a[k] for k in "xyz"], 1)
+        assert not np.isnan(P).any()
+        d2 = ((P[self.lo:self.hi, None, :] - P[None, :, :]) ** 2).sum(-1)
+        i, j = np.nonzero(d2 < self.cr ** 2)
+        i = i + self.lo
+        keep = j < i
+        i, j = i[keep], j[keep]
+        perm = np.random.default_rng(rank).permutation(len(i))         # (the device finds them in no particular order)
+        self.csend[:] = -7
+        self.csend[0] = len(i)
+        self.csend[2:2 + 2 * len(i):2] = i[perm]
+        self.csend[3:3 + 2 * len(i):2] = j[perm]
+
+    def mg_resolve(self, world):
+        blk = 2 + 2 * self.ccap
+        pairs = []
+        for r in range(world):
+            b = self.crecv[r * blk:(r + 1) * blk]
+            k = int(b[0])
+            pairs.append(np.stack([b[2:2 + 2 * k:2], b[3:3 + 2 * k:2]], 1))
+        pairs = np.concatenate(pairs) if pairs else np.zeros((0, 2), dtype=np.int32)
+        self._collide(pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64))
+
+    def mg_sweep(self, world, rank):
+        self._unpack(world, rank)
         P = np.stack([self.a[k] for k in "xyz"], 1)
         assert not np.isnan(P).any()
         d2 = ((P[:, None, :] - P[None, :, :]) ** 2).sum(-1)
         i, j = np.nonzero(np.tril(d2 < self.cr ** 2, -1))
+        self._collide(i, j)
+
+    def _collide(self, i, j):
         order = np.lexsort((j, i))
         self.ncand = len(order)
         v = {k: self.a[k] for k in ("vx", "vy", "vz")}
@@ -131,12 +169,12 @@ def make_state(n, seed=5):
     return [pos[0], pos[1], pos[2], vel[0], vel[1], vel[2]]
 
 
-def run_sim(n, rank, world, steps, comm):
+def run_sim(n, rank, world, steps, comm, replicated=False):
     cr = 3.385137501286538e-10
     p, _ = PR.cube_params(n=n)
     lo, hi = shard_range(n, rank, world)
     eng = NumpyShardEngine(n, lo, hi, cr)
-    sim = ShardedSimulation(p, rank, world, engine=eng, comm=comm)
+    sim = ShardedSimulation(p, rank, world, engine=eng, comm=comm, replicated_detect=replicated)
     sim.upload(*make_state(n))
     tot = None
     for s in range(steps):
@@ -145,12 +183,12 @@ def run_sim(n, rank, world, steps, comm):
     return sim, tot
 
 
-def _worker(rank, world, port, n, steps, q):
+def _worker(rank, world, port, n, steps, q, replicated=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sim, tot = run_sim(n, rank, world, steps, TorchComm(rank, world))
+        sim, tot = run_sim(n, rank, world, steps, TorchComm(rank, world), replicated)
         full = sim.download()
         if rank == 0:
             q.put(({k: v for k, v in full.items()}, tot))
@@ -204,15 +242,17 @@ class _NoComm:
     def allreduce_sum_ints(self, v): return list(v)
 
 
-@pytest.mark.parametrize("n,world", [(240, 2), (251, 2), (251, 3), (253, 8)])     # equal and unequal shards; 8 = the rank count of BASELINE configs[4]
-def test_ranks_equal_one_rank(n, world):
+# equal and unequal shards; 8 = the rank count of BASELINE configs[4]; detection sharded by index (two collectives per step:
+# positions, then the candidate pairs every rank found for its own particles) and, once, the replicated form
+@pytest.mark.parametrize("n,world,replicated", [(240, 2, False), (251, 2, False), (251, 3, False), (253, 8, False), (251, 3, True)])
+def test_ranks_equal_one_rank(n, world, replicated):
     steps = 6
     ref_sim, ref_tot = run_sim(n, 0, 1, steps, _NoComm())
     ref = ref_sim.engine.download()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q, replicated)) for r in range(world)]
     for p in procs:
         p.start()
     got, tot = _first_result(q, procs, 120)
