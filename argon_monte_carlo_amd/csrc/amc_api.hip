@@ -229,7 +229,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->s_slab2 = nullptr; c->extra_buf[0] = c->extra_buf[1] = nullptr; c->extra_count = nullptr; c->max_extra = 0;
     c->stream2 = nullptr; c->ev_detect = c->ev_stream = nullptr;
     c->ovl_flags = nullptr; c->ovl_tick = 0;
-    c->ovl_sync_values = !(getenv("AMC_OVERLAP_SYNC") && !strcmp(getenv("AMC_OVERLAP_SYNC"), "event"));
+    c->ovl_sync_values = getenv("AMC_OVERLAP_SYNC") && !strcmp(getenv("AMC_OVERLAP_SYNC"), "value");
     // AMC_OVERLAP: 1 the streaming pass of step s + 1 runs beside the resolve of sweep s inside amc_run, on a second stream;
     // 2 the same kernels in order on one stream (debugging); 0 the plain sequence (the default: measured on MI355X the resolve
     // kernels take twice as long beside the pass's memory traffic, which with the fix-up kernel and the two cross-stream

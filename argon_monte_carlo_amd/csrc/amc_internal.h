@@ -183,8 +183,8 @@ struct amc_ctx {
     hipStream_t stream2;      // the overlapped streaming pass runs here
     hipEvent_t ev_detect, ev_stream;
     unsigned int *ovl_flags;  // two words (64 bytes apart) the streams of an overlapped run signal each other through
-    unsigned int ovl_tick;    // (hipStreamWriteValue32 / hipStreamWaitValue32: a dependency costs ~2 us instead of the ~8 us of an
-    int ovl_sync_values;      // event record + wait pair, tools/ubench_xstream.hip; AMC_OVERLAP_SYNC=event selects the events)
+    unsigned int ovl_tick;    // (AMC_OVERLAP_SYNC=value: hipStreamWriteValue32 / hipStreamWaitValue32 instead of event record + wait —
+    int ovl_sync_values;      // ~2 us per dependency instead of ~8, tools/ubench_xstream.hip, but the resolve suffers more: DESIGN 4.2)
     int64_t ovl_steps;        // steps run overlapped so far
     int overlap_mode;         // AMC_OVERLAP: 1 (default) two streams, 2 the same kernels in order on one stream (debug), 0 off
     amc_resolve_ws W;

@@ -415,8 +415,10 @@ def main():
         sim.upload(*init)
         step = lambda k: sim.run(c["dt"], k)          # noqa: E731
         parallelism = (f"index-range shards x{world}: streaming pass (drift, walls, bounds) on the shard, one all-gather per step "
-                       "(positions + changed velocities, RCCL), then list build + p-p sweep of the WHOLE system REPLICATED on "
-                       "every rank (per-rank sweep time grows with the total particle count; DESIGN.md 6)")
+                       "(positions + changed velocities, RCCL), list build of the WHOLE system on every rank, " +
+                       ("detection of the whole system REPLICATED on every rank, " if sim.replicated_detect else
+                        "detection SHARDED by index (own particles against everybody) + a second all-gather of the candidate pairs, ") +
+                       "ordered resolve REPLICATED on every rank (DESIGN.md 6)")
         engines = [sim.engine]
 
     def sync():

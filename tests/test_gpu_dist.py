@@ -136,6 +136,14 @@ def test_ranks_on_one_gpu_equal_single_engine(kind, n, steps, world):
     assert npaths == ref_npaths and np.array_equal(counts, ref_counts)
 
 
+@pytest.mark.parametrize("kind,n,steps,world", [("cube", 30000, 8, 2), ("pore", 60001, 6, 2), ("cube", 100003, 10, 3), ("pore", 500001, 30, 2)])
+def test_detection_sharded_by_index_equals_single_engine(kind, n, steps, world, monkeypatch):
+    """The two-collective form (a rank examines its own particles against everybody, candidate pairs all-gathered)
+    forced at sizes where the driver would pick the replicated one: state, counters, histograms == the single engine."""
+    monkeypatch.setenv("AMC_MG_REPLICATED", "0")
+    test_ranks_on_one_gpu_equal_single_engine(kind, n, steps, world)
+
+
 @pytest.mark.parametrize("kind,n,steps", [("cube", 200000, 20), ("pore", 500001, 12)])
 def test_two_devices_over_rccl_equal_single_engine(kind, n, steps):
     """One rank per DEVICE, collectives on the device tensors over backend "nccl" (= RCCL over xGMI): the replacement of

@@ -7,7 +7,7 @@ import os
 import shutil
 import sys
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = "gpurun_out/prof"
 os.makedirs("profiles", exist_ok=True)
 
@@ -66,6 +66,8 @@ import bench  # noqa: E402
 for f in sorted(glob.glob(f"profiles/{ROUND}_bench_*.json")):
     d = json.loads(open(f).read())
     if d.get("roofline"):
+        if d["roofline"].get("bound") != "hbm":
+            continue
         t, src = bench.committed_traffic(d["config"]["workload"], d["roofline"]["kernel_class"], ROUND)
         d["roofline"]["traffic"], d["roofline"]["traffic_source"] = t, src
         open(f, "w").write(json.dumps(d) + "\n")
