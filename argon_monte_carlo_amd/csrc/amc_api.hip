@@ -699,7 +699,9 @@ static int run_overlapped(amc_ctx *c, double dt, int64_t nsteps)
             // (recorded above, BEHIND the detect kernel of step s - 1 and in front of its resolve kernels, which follow here)
             AMC_HIP(c, amc_launch_resolve(c, true));
         }
-        AMC_HIP(c, amc_launch_stream_ovl(c, dt, st, cur, prev_epoch, sp));
+        static const bool split = getenv("AMC_OVERLAP_SPLIT") && atoi(getenv("AMC_OVERLAP_SPLIT")) != 0;    // (experiment)
+        AMC_HIP(c, amc_launch_stream_ovl(c, dt, st, cur, prev_epoch, sp, !split));
+        if (split) AMC_HIP(c, amc_launch_bin_ovl(c, 1 - cur, prev_epoch, sp));
         if (two) {
             if (c->ovl_sync_values) {
                 AMC_HIP(c, hipStreamWriteValue32(c->stream2, c->ovl_flags + 16, c->ovl_tick, 0));

@@ -27,10 +27,11 @@
 // kernels; this one serves the stage API)
 __global__ __launch_bounds__(256) void k_bin_lists(const double *__restrict__ x, const double *__restrict__ y,
                                                    const double *__restrict__ z, long long n, amc_grid G, amc_lists B,
-                                                   amc_dev_counters *cnt)
+                                                   amc_dev_counters *cnt, amc_ovl V)
 {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
+    if (V.skip_epoch && (unsigned int)(V.adj_head[p] >> 32) == V.skip_epoch) return;      // (overlapped run: filed by the fix-up kernel)
     bool outside = false;
     amc_list_insert(G, B, (int)p, x[p], y[p], z[p], &outside);
     if (outside) atomicOr(&cnt->flags, 8ULL);
@@ -284,8 +285,23 @@ hipError_t amc_launch_bin(amc_ctx *c)
     const long long n = c->n;
     c->B.epoch++;
     amc_prof_begin(c, AMC_K_BIN_COUNT);
+    amc_ovl V;
+    V.adj_head = nullptr; V.skip_epoch = 0;
     AMC_LAUNCH(c, k_bin_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), c->S.x, c->S.y, c->S.z, n,
-                       c->G, c->B, c->d_cnt);
+                       c->G, c->B, c->d_cnt, V);
+    amc_prof_end(c);
+    return hipGetLastError();
+}
+
+// overlapped run, experiment AMC_OVERLAP_SPLIT=1: the pass's list build as a kernel of its own behind the streaming part
+hipError_t amc_launch_bin_ovl(amc_ctx *c, int to, unsigned int skip_epoch, hipStream_t stream)
+{
+    const long long n = c->n;
+    amc_ovl V;
+    V.adj_head = c->W.adj_head; V.skip_epoch = skip_epoch;
+    amc_prof_begin(c, AMC_K_BIN_COUNT);
+    AMC_LAUNCH_ON(c, stream, k_bin_lists, dim3((unsigned)((n + 255) / 256)), dim3(256), c->S_buf[to].x, c->S_buf[to].y, c->S_buf[to].z, n,
+                  c->G, c->B_buf[to], c->d_cnt, V);
     amc_prof_end(c);
     return hipGetLastError();
 }

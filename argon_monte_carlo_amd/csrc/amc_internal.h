@@ -275,8 +275,10 @@ void amc_prof_collect(amc_ctx *c);
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin = false);
 // the overlapped run (amc_stream.hip): the streaming pass of the next step while the sweep is being resolved,
 // and the fix-up kernel that joins the two
-hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, unsigned int skip_epoch, hipStream_t stream);
+hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, unsigned int skip_epoch, hipStream_t stream,
+                                 bool build_lists = true);
 hipError_t amc_launch_fixup(amc_ctx *c, double dt, int stages, int from, unsigned int sweep_epoch);
+hipError_t amc_launch_bin_ovl(amc_ctx *c, int to, unsigned int skip_epoch, hipStream_t stream);
 hipError_t amc_launch_bin(amc_ctx *c);                 // stand-alone list build over all n particles (stages, multi-GPU)
 hipError_t amc_launch_detect(amc_ctx *c);              // binned or all-pairs, fills W.cand_* / counters.cand_count
 hipError_t amc_launch_detect_own(amc_ctx *c);          // multi-GPU: own index range against everybody, into the candidate block

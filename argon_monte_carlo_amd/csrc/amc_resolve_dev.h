@@ -175,25 +175,32 @@ AMC_DEV void rs_store_hist(const amc_resolve_ws &W, int h, const double4 &r, boo
 // one hit inside an emulation: resolve p1 (= j, lower index) / p2 (= i) in registers, log events + history.
 // Returns true if the particles moved.
 AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj,
-                    int si, int phase, long long cell, rs_wide *wd = nullptr)
+                    int si, int phase, long long cell, rs_wide *wd_in = nullptr)
 {
     const amc_resolve_ws &W = A.W;
+    // (the wide kernel's hooks are read ONCE, into registers: the structure itself sits in private memory — it is reached
+    // through a pointer that is null in the ordered workgroup — and every field access there is a memory round trip of its own)
+    const bool wide = wd_in != nullptr;
+    rs_wide wd;
+    if (wide) wd = *wd_in;
     // the hit's pair of history entries (h: particle j, h + 1: particle i); its events use the same two indices
     int h = -1;
-    if (wd) {
+    bool unval = false;
+    if (wide) {
         // every candidate of the cluster brings TWO pairs of entries (4c, 4c + 2): hit q takes the first pairs in the order
         // of the candidate list, then the second ones (a cluster that pulled a particle in usually hits once more than it has
         // candidates); beyond that the counter — unpublishable here, so the ordered workgroup redoes the cluster
-        const int q = (*wd->used)++;
-        if (q < wd->ncnd) h = 4 * wd->cnd[q];
-        else if (q < 2 * wd->ncnd) h = 4 * wd->cnd[q - wd->ncnd] + 2;
-        if (h < 0) { h = wd->h_off + rs_count_add(&sh->nhist, 2); *wd->unval = 1; }
+        const int q = (*wd.used)++;
+        if (q < wd.ncnd) h = 4 * wd.cnd[q];
+        else if (q < 2 * wd.ncnd) h = 4 * wd.cnd[q - wd.ncnd] + 2;
+        if (h < 0) { h = wd.h_off + rs_count_add(&sh->nhist, 2); *wd.unval = 1; }
+        unval = *wd.unval != 0;
     } else {
         h = rs_count_add(&sh->nhist, 2);
     }
     const bool room = h + 1 < W.max_hist;
     if (!room) sh->ovf = 1;
-    const int gen = wd ? wd->gen : sh->cur_round;
+    const int gen = wide ? wd.gen : sh->cur_round;
     if (room) { W.ev_gen[h] = 0; W.ev_gen[h + 1] = 0; }
     auto emit = [&](int which, double tot, double px, double py, double pz) {
         if (!room) return;
@@ -211,22 +218,22 @@ AMC_DEV bool rs_hit(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_parti
     atomicAdd(&W.sl_hits[si], fail ? 0x10000 : 1);
     if (room) {
         // (a failed hit moved nothing: its pair of entries stays empty — round 0 never matches a slot's round)
-        rs_store_hist(W, h, rs_hist_make(p1.x, p1.y, p1.z, sj, fail ? 0 : gen), wd != nullptr);
-        rs_store_hist(W, h + 1, rs_hist_make(p2.x, p2.y, p2.z, si, fail ? 0 : gen), wd != nullptr);
-        if (wd && !*wd->unval) {
+        rs_store_hist(W, h, rs_hist_make(p1.x, p1.y, p1.z, sj, fail ? 0 : gen), wide);
+        rs_store_hist(W, h + 1, rs_hist_make(p2.x, p2.y, p2.z, si, fail ? 0 : gen), wide);
+        if (wide && !unval) {
             // the wave publishes and probes the two new positions after the emulation (amc_clusters.hip); the empty
             // pair of a failed hit keeps its place in the list (pad = 1: neither published nor probed)
-            const int it = atomicAdd(wd->nitems, 2);
-            if (it + 2 <= wd->cap) {
-                if (*wd->it0 < 0) *wd->it0 = it;             // (the owner's later pairs follow it directly only if no other lane of
+            const int it = atomicAdd(wd.nitems, 2);
+            if (it + 2 <= wd.cap) {
+                if (*wd.it0 < 0) *wd.it0 = it;               // (the owner's later pairs follow it directly only if no other lane of
                                                             // the wave appended in between: cw_probe_overlay checks before it relies on that)
                 cw_item a, b;
-                a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd->own; a.p = pj; a.pad = fail | (wd->gen << 1);
-                b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd->own; b.p = pi; b.pad = fail | (wd->gen << 1);
-                wd->items[it] = a;
-                wd->items[it + 1] = b;
+                a.x = p1.x; a.y = p1.y; a.z = p1.z; a.h = h; a.own = wd.own; a.p = pj; a.pad = fail | (wd.gen << 1);
+                b.x = p2.x; b.y = p2.y; b.z = p2.z; b.h = h + 1; b.own = wd.own; b.p = pi; b.pad = fail | (wd.gen << 1);
+                wd.items[it] = a;
+                wd.items[it + 1] = b;
             } else {
-                *wd->unval = 1;
+                *wd.unval = 1;
             }
         }
     }
@@ -246,16 +253,24 @@ AMC_DEV int rs_pore_cell(const rs_geom &P, double x, double y, double z, int gx,
 
 // The (at most two) integers k with  k*d - ov < v < (k+1)*d  (Pore:527-529 with k = 2*layer+group-offset): the core
 // cell of v and, if v lies in the overlap strip, the next one.  INT_MIN marks "none".
-AMC_DEV void rs_axis_k(double v, double d, double inv_d, double ov, int &ka, int &kb)
+AMC_DEV void rs_axis_k(double v, double d, double inv_d, double ov, int &ka_out, int &kb_out)
 {
-    ka = kb = (int)0x80000000;
+    // (found in locals and handed out once: written through the references inside the loop, the callers' arrays stayed in
+    // private memory — 230 scratch accesses in the pore instantiation of the wide cluster kernel)
+    int ka = (int)0x80000000, kb = (int)0x80000000;
     const double f = floor(v * inv_d);
-    if (!(f > -1.0e9 && f < 1.0e9)) return;
-    for (int dk = -1; dk <= 1; dk++) {
-        const int k = (int)f + dk;
-        const double lo = (double)k * d - ov, hi = (double)(k + 1) * d;
-        if (lo < v && v < hi) { if (ka == (int)0x80000000) ka = k; else kb = k; }
+    if (f > -1.0e9 && f < 1.0e9) {
+#pragma unroll
+        for (int dk = -1; dk <= 1; dk++) {
+            const int k = (int)f + dk;
+            const double lo = (double)k * d - ov, hi = (double)(k + 1) * d;
+            const bool in = lo < v && v < hi;
+            const bool first = ka == (int)0x80000000;
+            kb = (in && !first) ? k : kb;
+            ka = (in && first) ? k : ka;
+        }
     }
+    ka_out = ka; kb_out = kb;
 }
 AMC_DEV void rs_pore_ks(const rs_args &A, const amc_particle &q, int *k)
 {
@@ -347,6 +362,8 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, a
         // Lanes of a wave hold different pairs whose first shared colour group differs; with the hit inside the group
         // loop the wave would run the (large) collision path once per group.  So each lane first SEARCHES its next
         // group with a shared cell (cheap integer work), then all lanes resolve together, then the search resumes.
+        // (Tried in round 3: the shared layer per axis and group bit computed up front, six evaluations instead of two cell
+        // ids per group searched — slower, 7.2 -> 8.2 us per pair: the search usually ends at one of the first groups.)
         int g = 0;
         bool ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);      // unchanged until a hit moves the pair
         for (;;) {

@@ -354,7 +354,8 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
 
 // ---- the overlapped run's two launches (whole range in one context, cube / specular pore, binned detector) ---------------------
 // `from`: the buffer (0 / 1) holding the state and the lists of the sweep in flight; the pass writes the other one.
-hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, unsigned int skip_epoch, hipStream_t stream)
+hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, unsigned int skip_epoch, hipStream_t stream,
+                                 bool build_lists)
 {
     const int to = 1 - from;
     amc_lists &Bn = c->B_buf[to];
@@ -370,10 +371,10 @@ hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, un
     amc_prof_begin(c, AMC_K_DRIFT_WALLS);
     if (c->P.geometry == AMC_GEOM_CUBE)
         AMC_LAUNCH_ON(c, stream, k_stream<AMC_GEOM_CUBE>, dim3(blocks), dim3(256), c->S_buf[from], c->S_buf[to], c->P, O, dt, stages,
-                      0LL, (long long)c->n, 0, 0, c->G, Bn, 1, L, C, V);
+                      0LL, (long long)c->n, 0, 0, c->G, Bn, build_lists ? 1 : 0, L, C, V);
     else
         AMC_LAUNCH_ON(c, stream, k_stream<AMC_GEOM_PORE>, dim3(blocks), dim3(256), c->S_buf[from], c->S_buf[to], c->P, O, dt, stages,
-                      0LL, (long long)c->n, 0, 0, c->G, Bn, 1, L, C, V);
+                      0LL, (long long)c->n, 0, 0, c->G, Bn, build_lists ? 1 : 0, L, C, V);
     amc_prof_end(c);
     return hipGetLastError();
 }
