@@ -407,6 +407,8 @@ hipError_t amc_launch_detect(amc_ctx *c)
         const bool extras = c->B.extra != nullptr;
         const int slot = (c->B.extra == c->extra_buf[1]) ? 1 : 0;
         static const int bs = getenv("AMC_DETECT_BS") ? atoi(getenv("AMC_DETECT_BS")) : 256;      // (experiments: 64 / 128 / 256)
+        // (occupancy is not what bounds this kernel: capped at 4 waves per SIMD instead of 5 it takes the same 36.7 us at
+        // N = 1e6, at 2 it takes 59 — it runs at the rate of its random requests)
         AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + bs - 1) / bs) + (extras ? 4u : 0u)), dim3(bs), c->G, c->B, n, cr2i,
                    c->G.cr_probe, c->W.max_cand, c->d_cnt, D, (const int *)(extras ? c->extra_count + slot : nullptr),
                    c->max_extra);

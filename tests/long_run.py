@@ -36,7 +36,11 @@ s = eng.download()
 counts, npaths = eng.histograms()
 v2 = float(np.sum(s["vx"] ** 2 + s["vy"] ** 2 + s["vz"] ** 2))
 outside = int(eng.stage_bounds())
+import hashlib
+state_sha = hashlib.sha256(b"".join(np.ascontiguousarray(s[k]).tobytes() for k in ("x", "y", "z", "vx", "vy", "vz", "d", "dx", "dy", "dz"))).hexdigest()
 out = {"workload": workload, "n": int(p.n), "steps": steps, "gpu_seconds": round(t_gpu, 3),
+       "overlapped_run": eng.overlap_stats(), "final_state_sha256": state_sha,
+       "histograms_sha256": hashlib.sha256(np.ascontiguousarray(counts).tobytes()).hexdigest(),
        "particle_steps_per_s": p.n * steps / t_gpu,
        "counters": {k: int(tot[k]) for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors", "flags")},
        "kinetic_energy_relative_drift": abs(v2 / v2_0 - 1.0),
@@ -46,7 +50,7 @@ out = {"workload": workload, "n": int(p.n), "steps": steps, "gpu_seconds": round
 out["ok"] = bool(out["kinetic_energy_relative_drift"] < 1e-9 and outside == 0 and npaths == tot["n_paths"] and
                  tot["flags"] == 0 and out["all_finite"] and out["histogram_rows_le_total"])
 os.makedirs("gpurun_out", exist_ok=True)
-with open(f"gpurun_out/long_{workload}_{steps}.json", "w") as f:
+with open(f"gpurun_out/long_{workload}_{steps}" + ("_overlap" if out["overlapped_run"]["steps"] else "") + ".json", "w") as f:
     f.write(json.dumps(out) + "\n")
 print(json.dumps(out))
 sys.exit(0 if out["ok"] else 1)
