@@ -329,6 +329,31 @@ class SurfaceEnergies:
                     os.environ["AMC_GAP_WORKERS"] = "0"
         return [self.gap(z) for z in zs]
 
+    def gap_start(self, z_values):
+        """Hand the contact heights of a case to the worker processes and return at once; ``gap_finish`` collects the
+        energies.  None when there are no workers (or nothing to do): the caller evaluates them when it needs them."""
+        zs = [float(z) for z in z_values]
+        if not zs:
+            return None
+        pool = self._get_pool()
+        if pool is None:
+            return None
+        try:
+            return (pool, pool.start(zs), zs)
+        except Exception:
+            SurfaceEnergies._shutdown_pool()
+            return None
+
+    def gap_finish(self, handle):
+        pool, count, zs = handle
+        try:
+            return pool.finish(count)
+        except Exception:
+            SurfaceEnergies._shutdown_pool()            # (a dead worker: this process does it, now and from now on)
+            import os
+            os.environ["AMC_GAP_WORKERS"] = "0"
+            return [self.gap(z) for z in zs]
+
     def gap(self, z_value):
         z_value = float(z_value)
         m = (self.t_cold - self.t_hot) / self.gap_height                                   # Temp:144
@@ -438,6 +463,30 @@ class _GapWorkers:
                 out[base + k] = st.unpack(buf)[0]
         return out
 
+    # the two halves of map(), for callers that have something else to do while the workers integrate: every request is
+    # written at once (worker k gets requests k, k + nw, ...: a pipe holds thousands of them and a worker answers in order),
+    # the answers are read later
+    def start(self, zs):
+        import os
+        st, nw = self._struct, len(self.workers)
+        for k, z in enumerate(zs):
+            os.write(self.workers[k % nw][1], st.pack(z))
+        return len(zs)
+
+    def finish(self, count):
+        import os
+        st, nw = self._struct, len(self.workers)
+        out = [0.0] * count
+        for k in range(count):
+            buf = b""
+            while len(buf) < 8:
+                chunk = os.read(self.workers[k % nw][2], 8 - len(buf))
+                if not chunk:
+                    raise RuntimeError("a gap-energy worker went away")
+                buf += chunk
+            out[k] = st.unpack(buf)[0]
+        return out
+
     def close(self):
         import os
         import signal
@@ -488,11 +537,27 @@ def drive_energised_cases(hooks, sampler, energies):
     gap energies of the case are evaluated together afterwards (``gap_many``: worker processes when there are several)."""
     mom = cold = hot = 0
     had_m = had_c = had_h = False
+    # The gap case's integrals (mpmath.quad, ~0.8 ms each, five per step at N = 1e6) are half of the hand-over's host time.
+    # Its mask reads positions and prior positions only (Temp:720-721), and what the two cases before it change — particles
+    # parked on the planes z = h_oa -+ r_ar outside the gap zone — cannot enter or leave it: so the gap case's hits are
+    # looked at ONCE MORE, ahead of case 3, and their integrals run in the worker processes while cases 3 and 4 are handled.
+    # Nothing is assumed: when the gap case's turn comes its hits are taken again, and the early energies are used only if
+    # particle indices, contact heights and solve flags are identical (else they are discarded and evaluated as before).
+    early = None
+    if getattr(hooks, "early_gap", False) and hasattr(energies, "gap_start"):
+        e_idx, _, e_cz, e_ok = hooks.wall_hits(GAP_CASE)
+        if len(e_idx):
+            h = energies.gap_start(np.asarray(e_cz)[np.flatnonzero(np.asarray(e_ok))].tolist())
+            if h is not None:
+                early = (np.array(e_idx), np.array(e_cz), np.array(e_ok), h)
     with (sampler.session() if hasattr(sampler, "session") else _NoSession(sampler)):
         for case in CASES:
             idx, normals, contact_z, ok = hooks.wall_hits(case)
             n = len(idx)
             if n == 0:
+                if case == GAP_CASE and early is not None:
+                    energies.gap_finish(early[3])           # (drain the workers' answers: nothing hit after all)
+                    early = None
                 continue
             if hasattr(sampler, "sample_case"):
                 dirs = sampler.sample_case(normals, ok)
@@ -503,7 +568,14 @@ def drive_energised_cases(hooks, sampler, energies):
                         dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
             good = np.flatnonzero(np.asarray(ok))
             Es = np.zeros(n)
-            if case == GAP_CASE:
+            if case == GAP_CASE and early is not None:
+                e_vals = energies.gap_finish(early[3])
+                if np.array_equal(early[0], idx) and np.array_equal(early[1], contact_z) and np.array_equal(early[2], ok):
+                    Es[good] = e_vals
+                else:
+                    Es[good] = energies.gap_many(np.asarray(contact_z)[good].tolist())
+                early = None
+            elif case == GAP_CASE:
                 if hasattr(energies, "gap_many"):
                     Es[good] = energies.gap_many(np.asarray(contact_z)[good].tolist())
                 else:

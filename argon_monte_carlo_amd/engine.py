@@ -239,6 +239,7 @@ class ShardEngine(Engine):
 class EnergisedEngine(Engine):
     """Engine + the energised-wall hand-over (Temp:705-758): ``wall_hits`` / ``wall_apply`` are the hooks that
     ``energised.drive_energised_cases`` drives once per case."""
+    early_gap = True            # wall_hits(case) may be called ahead of its turn (it changes nothing): the gap case's integrals start early
 
     def temp_begin(self, dt):
         self._ck(self.lib.amc_temp_begin(self._ctx, float(dt)))

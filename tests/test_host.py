@@ -266,6 +266,28 @@ def test_gap_workers_can_be_started_ahead_of_the_gpu_context(monkeypatch):
     assert 0 < src.index("SurfaceEnergies(consts, start_workers=True)") < src.index("EnergisedEngine(params)")
 
 
+def test_gap_energies_started_early_equal_the_serial_ones(monkeypatch):
+    """gap_start / gap_finish (the integrals run in the workers while the host handles other cases): same values, same
+    order, several batches in a row; without workers gap_start declines."""
+    from argon_monte_carlo_amd.energised import SurfaceEnergies
+    _, c = PR.pore_params(n=100, energised=True)
+    en = SurfaceEnergies(c)
+    z0 = c["open_air_height"] + c["hot_coating_height"]
+    zs = [z0 + f * c["gap_height"] for f in (0.05, 0.3, 0.31, 0.62, 0.9, 0.97, 0.5)]
+    want = [en.gap(z) for z in zs]
+    monkeypatch.setenv("AMC_GAP_WORKERS", "3")
+    try:
+        for batch in (zs, zs[:1], zs[2:5]):
+            h = en.gap_start(batch)
+            assert h is not None
+            assert en.gap_finish(h) == [want[zs.index(z)] for z in batch]
+        assert en.gap_start([]) is None
+    finally:
+        SurfaceEnergies._shutdown_pool()
+    monkeypatch.setenv("AMC_GAP_WORKERS", "0")
+    assert en.gap_start(zs) is None
+
+
 def test_gap_energies_survive_a_dead_worker(monkeypatch):
     """A worker that went away (killed, out of memory) must not cost the step: gap_many notices, does the integrals in
     this process and stops using workers."""
