@@ -50,6 +50,9 @@ SIGNATURES = {
                                       C.c_double, C.c_int, C.c_void_p, _dp]),
     "amc_wall_hits": (C.c_int, [_ctx, C.c_int, _i32p, _dp, _dp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_wall_apply": (C.c_int, [_ctx, C.c_int, _dp, _dp, C.c_size_t, _dp, _dp]),
+    "amc_wall_park": (C.c_int, [_ctx, C.c_int, _dp, C.c_size_t]),
+    "amc_wall_finish": (C.c_int, [_ctx, C.c_int, _dp, C.c_size_t, _dp, _dp]),
+    "amc_wall_hits_again": (C.c_int, [_ctx]),
     "amc_drain_paths": (C.c_int, [_ctx, C.POINTER(AmcPathRecord), C.c_size_t, C.POINTER(C.c_size_t)]),
     "amc_paths_pending": (C.c_int, [_ctx, C.POINTER(C.c_size_t)]),
     "amc_histograms": (C.c_int, [_ctx, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -179,6 +179,8 @@ void amc_destroy(amc_ctx *c)
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->T.pin) hipHostFree(c->T.pin);
     if (c->T.count) hipFree(c->T.count);
+    if (c->T.def_idx) hipFree(c->T.def_idx);
+    if (c->T.def_dir) hipFree(c->T.def_dir);
     { void *td[] = {c->TD.idx, c->TD.count, c->TD.t, c->TD.contact, c->TD.normal, c->TD.dir, c->TD.Es, c->TD.dpz, c->TD.dE, c->TD.ok};
       for (void *q : td) if (q) hipFree(q); }
     if (c->cand_send) hipFree(c->cand_send);
@@ -238,6 +240,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     c->ovl_steps = 0;
     c->T.idx = nullptr; c->T.count = nullptr; c->T.t = c->T.contact = c->T.normal = c->T.dir = c->T.Es = c->T.dpz = c->T.dE = nullptr;
     c->T.ok = nullptr; c->T.cap = 0; c->T.last_case = -1; c->T.last_n = 0; c->T.pre_case = -1; c->T.pin = nullptr;
+    c->T.def_idx = nullptr; c->T.def_dir = nullptr; c->T.def_case = -1; c->T.def_n = 0;
     memset(&c->out, 0, sizeof c->out); memset(&c->h_prev, 0, sizeof c->h_prev);
     c->d_lay = nullptr; c->d_banks = nullptr; c->d_rec = nullptr; c->d_hist = nullptr; c->d_edges = nullptr;
     c->d_dbg = nullptr; c->w_slab = nullptr; c->s_slab = nullptr;

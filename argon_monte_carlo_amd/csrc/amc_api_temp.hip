@@ -18,7 +18,8 @@ static int temp_ensure(amc_ctx *c)
     const size_t o_count = place(64), o_idx = place(sizeof(int) * cap), o_t = place(sizeof(double) * cap),
                  o_contact = place(sizeof(double) * 3 * cap), o_normal = place(sizeof(double) * 3 * cap),
                  o_dir = place(sizeof(double) * 3 * cap), o_Es = place(sizeof(double) * cap), o_dpz = place(sizeof(double) * cap),
-                 o_dE = place(sizeof(double) * cap), o_ok = place(cap);
+                 o_dE = place(sizeof(double) * cap), o_ok = place(cap), o_dEs = place(sizeof(double) * cap),
+                 o_ddpz = place(sizeof(double) * cap), o_ddE = place(sizeof(double) * cap);
     void *hp = nullptr, *dp = nullptr;
     AMC_HIP(c, hipHostMalloc(&hp, off, hipHostMallocMapped));
     if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { hipHostFree(hp); return amc_fail(c, AMC_ERR_HIP, "hipHostGetDevicePointer failed"); }
@@ -32,6 +33,11 @@ static int temp_ensure(amc_ctx *c)
     T.h_count = (int *)(h + o_count); T.h_idx = (int *)(h + o_idx); T.h_contact = (double *)(h + o_contact);
     T.h_normal = (double *)(h + o_normal); T.h_dir = (double *)(h + o_dir); T.h_Es = (double *)(h + o_Es);
     T.h_dpz = (double *)(h + o_dpz); T.h_dE = (double *)(h + o_dE);
+    T.def_Es = (double *)(d + o_dEs); T.def_dpz = (double *)(d + o_ddpz); T.def_dE = (double *)(d + o_ddE);
+    T.h_def_Es = (double *)(h + o_dEs); T.h_def_dpz = (double *)(h + o_ddpz); T.h_def_dE = (double *)(h + o_ddE);
+    AMC_HIP(c, dalloc(&T.def_idx, cap));
+    AMC_HIP(c, dalloc(&T.def_dir, 3 * cap));
+    T.def_case = -1; T.def_n = 0;
     T.last_case = -1; T.last_n = 0; T.pre_case = -1;
     return AMC_OK;
 }
@@ -117,6 +123,69 @@ int amc_wall_apply(amc_ctx *c, int case_id, const double *dir_xyz, const double 
         if (dpz) dpz[s] = T.h_dpz[T.perm[s]];
         if (dE) dE[s] = T.h_dE[T.perm[s]];
     }
+    return AMC_OK;
+}
+
+// A case whose surface energies are not there yet (the gap case: mpmath integrals in worker processes, energised.py) can be
+// PARKED: amc_wall_park does everything of amc_wall_apply that does not depend on the energy — the completed path, the
+// counters, the particle at its contact point — so that the following cases' masks see what they have to see, and
+// amc_wall_finish sets the new velocities when the energies have arrived.  Exact as long as no later case hits a parked
+// particle before the finish (the driver checks the hit lists and finishes first if one does; amc_wall_hits_again makes
+// the library evaluate that case's hits anew, on the finished state).
+int amc_wall_park(amc_ctx *c, int case_id, const double *dir_xyz, size_t n)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_temp_ws &T = c->T;
+    if (!T.idx || T.last_case != case_id || (size_t)T.last_n != n)
+        return amc_fail(c, AMC_ERR_STATE, "amc_wall_park(case %d, n=%zu) does not match the pending amc_wall_hits(case %d, n=%d)", case_id, n, T.last_case, T.last_n);
+    if (T.def_case >= 0) return amc_fail(c, AMC_ERR_STATE, "amc_wall_park: case %d is still parked", T.def_case);
+    T.last_case = -1;
+    if (n == 0) return AMC_OK;
+    if (!dir_xyz) return AMC_ERR_INVALID;
+    for (size_t s = 0; s < n; s++) {
+        const int k = T.perm[s];
+        T.h_dir[3 * k] = dir_xyz[3 * s]; T.h_dir[3 * k + 1] = dir_xyz[3 * s + 1]; T.h_dir[3 * k + 2] = dir_xyz[3 * s + 2];
+        T.h_Es[k] = 0.0;
+    }
+    AMC_HIP(c, amc_launch_temp_apply(c, case_id, (int)n, true));
+    T.def_case = case_id; T.def_n = (int)n; T.def_perm = T.perm;
+    int pre = -1;
+    if (case_id < 9) {                          // (the next case's hits behind it, as in amc_wall_apply)
+        AMC_HIP(c, amc_launch_temp_hits(c, case_id + 1));
+        AMC_HIP(c, hipMemcpyAsync(T.h_count, T.count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        pre = case_id + 1;
+    }
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    T.pre_case = pre;
+    return AMC_OK;
+}
+
+int amc_wall_finish(amc_ctx *c, int case_id, const double *surface_energy, size_t n, double *dpz, double *dE)
+{
+    if (!c) return AMC_ERR_INVALID;
+    AMC_HIP(c, hipSetDevice(c->device));
+    amc_temp_ws &T = c->T;
+    if (T.def_case != case_id || (size_t)T.def_n != n)
+        return amc_fail(c, AMC_ERR_STATE, "amc_wall_finish(case %d, n=%zu) does not match the parked case %d (n=%d)", case_id, n, T.def_case, T.def_n);
+    T.def_case = -1;
+    if (n == 0) return AMC_OK;
+    if (!surface_energy) return AMC_ERR_INVALID;
+    for (size_t s = 0; s < n; s++) T.h_def_Es[T.def_perm[s]] = surface_energy[s];
+    AMC_HIP(c, amc_launch_temp_velocity(c, case_id, (int)n));
+    AMC_HIP(c, hipStreamSynchronize(c->stream));
+    for (size_t s = 0; s < n; s++) {
+        if (dpz) dpz[s] = T.h_def_dpz[T.def_perm[s]];
+        if (dE) dE[s] = T.h_def_dE[T.def_perm[s]];
+    }
+    return AMC_OK;
+}
+
+int amc_wall_hits_again(amc_ctx *c)
+{
+    if (!c) return AMC_ERR_INVALID;
+    c->T.pre_case = -1;             // the hits launched behind the last apply are not used: the next amc_wall_hits evaluates its case anew
+    c->T.last_case = -1;
     return AMC_OK;
 }
 

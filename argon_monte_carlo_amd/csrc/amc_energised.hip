@@ -107,22 +107,28 @@ __global__ __launch_bounds__(256) void k_temp_hits(amc_state S, amc_params P, in
     R.normal[3 * k] = c.n0; R.normal[3 * k + 1] = c.n1; R.normal[3 * k + 2] = c.n2;
 }
 
+// `park` (the gap case with its surface energies still being integrated on the host, amc_wall_park): everything of the
+// handler that does not depend on the energy — completed path (old velocity), counters, accumulators zeroed, particle at the
+// contact point — and the hit's particle and direction kept in `def_idx` / `def_dir`; k_temp_velocity finishes it.
 __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, amc_out O, int case_id, int n,
                                                     temp_records R, const double *__restrict__ dir,
                                                     const double *__restrict__ Es, double *__restrict__ dpz,
-                                                    double *__restrict__ dE)
+                                                    double *__restrict__ dE, int park, int *__restrict__ def_idx,
+                                                    double *__restrict__ def_dir)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (n < 0) n = min(*R.count, R.cap);        // device-RNG mode: the host never saw the count
     if (k >= n) return;
     dpz[k] = 0; dE[k] = 0;
+    if (park) { def_idx[k] = R.ok[k] ? R.idx[k] : -1; def_dir[3 * k] = dir[3 * k]; def_dir[3 * k + 1] = dir[3 * k + 1]; def_dir[3 * k + 2] = dir[3 * k + 2]; }
     if (!R.ok[k]) { atomicAdd(&O.banks[amc_bank_id()].n_fp_errors, 1ULL); atomicAdd(&O.banks[amc_bank_id()].n_wall, 1ULL); return; }
     const int p = R.idx[k];
     const double t = R.t[k];
     const double vx = S.vx[p], vy = S.vy[p], vz = S.vz[p];
-    double wvx, wvy, wvz;
-    const double v_magnitude = temp_accommodate(P, case_id, vx, vy, vz, Es[k], dir[3 * k], dir[3 * k + 1], dir[3 * k + 2], wvx,
-                                                wvy, wvz, dpz[k], dE[k]);
+    double wvx = vx, wvy = vy, wvz = vz;
+    const double v_magnitude = park ? sqrt(vx * vx + vy * vy + vz * vz)                       // Temp:377 (as in temp_accommodate)
+                                    : temp_accommodate(P, case_id, vx, vy, vz, Es[k], dir[3 * k], dir[3 * k + 1], dir[3 * k + 2],
+                                                       wvx, wvy, wvz, dpz[k], dE[k]);
     if (S.flag[p])                                                                           // Temp:391-395
         amc_emit(O, case_id + 1, 0, p, -1, 0, fabs(S.d[p] - fabs(v_magnitude * t)), fabs(S.dx[p] - fabs(vx * t)),
                  fabs(S.dy[p] - fabs(vy * t)), fabs(S.dz[p] - fabs(vz * t)));
@@ -132,6 +138,23 @@ __global__ __launch_bounds__(256) void k_temp_apply(amc_state S, amc_params P, a
     S.x[p] = R.contact[3 * k]; S.y[p] = R.contact[3 * k + 1]; S.z[p] = R.contact[3 * k + 2];   // Temp:402
     S.vx[p] = wvx; S.vy[p] = wvy; S.vz[p] = wvz;                                             // Temp:403
     atomicAdd(&O.banks[amc_bank_id()].n_wall, 1ULL);                                         // Temp:411,482,552
+}
+
+// the second half of a parked case: energy accommodation and the new velocity (Temp:377-388) from the velocity the particle
+// still has (nothing touched it since it was parked) and the surface energies that have arrived
+__global__ __launch_bounds__(256) void k_temp_velocity(amc_state S, amc_params P, int case_id, int n, const int *__restrict__ def_idx,
+                                                       const double *__restrict__ def_dir, const double *__restrict__ Es,
+                                                       double *__restrict__ dpz, double *__restrict__ dE)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    dpz[k] = 0; dE[k] = 0;
+    const int p = def_idx[k];
+    if (p < 0) return;                          // (a failed contact solve: counted when the case was parked)
+    double wvx, wvy, wvz;
+    temp_accommodate(P, case_id, S.vx[p], S.vy[p], S.vz[p], Es[k], def_dir[3 * k], def_dir[3 * k + 1], def_dir[3 * k + 2], wvx, wvy,
+                     wvz, dpz[k], dE[k]);
+    S.vx[p] = wvx; S.vy[p] = wvy; S.vz[p] = wvz;                                             // Temp:403
 }
 
 static temp_records make_records(amc_ctx *c)
@@ -152,11 +175,19 @@ hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id)
     return hipGetLastError();
 }
 
-hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n)
+hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n, bool park)
 {
     if (n <= 0) return hipSuccess;
     AMC_LAUNCH(c, k_temp_apply, dim3((n + 255) / 256), dim3(256), c->S, c->P, c->out, case_id, n,
-                       make_records(c), c->T.dir, c->T.Es, c->T.dpz, c->T.dE);
+                       make_records(c), c->T.dir, c->T.Es, c->T.dpz, c->T.dE, park ? 1 : 0, c->T.def_idx, c->T.def_dir);
+    return hipGetLastError();
+}
+
+hipError_t amc_launch_temp_velocity(amc_ctx *c, int case_id, int n)
+{
+    if (n <= 0) return hipSuccess;
+    AMC_LAUNCH(c, k_temp_velocity, dim3((n + 255) / 256), dim3(256), c->S, c->P, case_id, n, c->T.def_idx, c->T.def_dir,
+               c->T.def_Es, c->T.def_dpz, c->T.def_dE);
     return hipGetLastError();
 }
 
@@ -315,7 +346,7 @@ hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg)
         AMC_LAUNCH(c, k_temp_sample, dim3(rec_blocks), dim3(256), c->P, *cfg, case_id,
                            (unsigned int)c->out.step, R, D.dir + 3 * o, D.Es + o);
         AMC_LAUNCH(c, k_temp_apply, dim3(rec_blocks), dim3(256), c->S, c->P, c->out, case_id, -1, R,
-                           D.dir + 3 * o, D.Es + o, D.dpz + o, D.dE + o);
+                           D.dir + 3 * o, D.Es + o, D.dpz + o, D.dE + o, 0, (int *)nullptr, (double *)nullptr);
     }
     return hipGetLastError();
 }

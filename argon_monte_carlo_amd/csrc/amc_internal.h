@@ -145,6 +145,13 @@ struct amc_temp_ws {
     int pre_case;                // >= 0: the hits of this case are already in the records (launched behind the previous
                                  // case's apply kernel: one synchronisation serves both)
     std::vector<int> perm;       // sorted position -> record slot of the pending hits
+    // a PARKED case (amc_wall_park / amc_wall_finish: the gap case while its surface energies are still being integrated):
+    // particle (-1: failed solve) and direction of every hit in record order, the energies / results of the finishing kernel
+    int *def_idx;
+    double *def_dir, *def_Es, *def_dpz, *def_dE;    // (the last three: device views of pinned memory, host views below)
+    double *h_def_Es, *h_def_dpz, *h_def_dE;
+    int def_case, def_n;
+    std::vector<int> def_perm;
 };
 
 // device-RNG mode (amc_temp_cases_device): one record segment per energised case, kept until the next step
@@ -289,7 +296,8 @@ hipError_t amc_launch_commit(amc_ctx *c);               // the pending commit as
 struct amc_commit_args;
 amc_commit_args amc_make_commit_args(amc_ctx *c);       // amc_stream.hip
 hipError_t amc_launch_temp_hits(amc_ctx *c, int case_id);
-hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n);
+hipError_t amc_launch_temp_apply(amc_ctx *c, int case_id, int n, bool park = false);
+hipError_t amc_launch_temp_velocity(amc_ctx *c, int case_id, int n);
 hipError_t amc_launch_temp_cases_device(amc_ctx *c, const amc_temp_rng *cfg);
 hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack);
 int amc_kin_banks(void);         // banks of the velocity-change list in an exchange block

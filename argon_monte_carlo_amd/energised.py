@@ -535,25 +535,51 @@ def drive_energised_cases(hooks, sampler, energies):
     Per hit the reference draws the direction first and evaluates the surface energy second (Temp:367-368 and
     alike); the energy consumes no random numbers, so all directions of a case are drawn first (``sample_case``) and the
     gap energies of the case are evaluated together afterwards (``gap_many``: worker processes when there are several)."""
-    mom = cold = hot = 0
-    had_m = had_c = had_h = False
-    # The gap case's integrals (mpmath.quad, ~0.8 ms each, five per step at N = 1e6) are half of the hand-over's host time.
-    # Its mask reads positions and prior positions only (Temp:720-721), and what the two cases before it change — particles
-    # parked on the planes z = h_oa -+ r_ar outside the gap zone — cannot enter or leave it: so the gap case's hits are
-    # looked at ONCE MORE, ahead of case 3, and their integrals run in the worker processes while cases 3 and 4 are handled.
-    # Nothing is assumed: when the gap case's turn comes its hits are taken again, and the early energies are used only if
-    # particle indices, contact heights and solve flags are identical (else they are discarded and evaluated as before).
+    # The gap case's integrals (mpmath.quad, ~1 ms each, five per step at N = 1e6) are half of the hand-over's host time.  Two
+    # things take them off the critical path; neither assumes anything that is not checked:
+    # * EARLY START.  The gap mask reads positions and prior positions only (Temp:720-721), and what the two cases before it
+    #   change — particles parked on the planes z = h_oa -+ r_ar outside the gap zone — cannot enter or leave it: the gap
+    #   case's hits are looked at once more ahead of case 3 (wall_hits changes nothing) and their contact heights go to the
+    #   worker processes.  When the gap case's turn comes its hits are taken again and the early energies are used only if
+    #   particle indices, contact heights and solve flags are identical.
+    # * PARKING.  At its turn the gap case is parked (hooks.wall_park: completed paths, counters, particles at their contact
+    #   points — all the following masks read) and finished (hooks.wall_finish: new velocities, dp_z) after case 9, when the
+    #   energies have had the whole hand-over to arrive.  A parked particle keeps its old velocity meanwhile; should a later
+    #   case hit one, the gap case is finished first and that case's hits are evaluated anew.
+    # The per-case sums are folded in case order at the end: the same additions in the same order as the reference's loop.
+    import os
+    part = {}                                   # case -> (m_case, e_case, any good hit)
     early = None
+    can_park = hasattr(hooks, "wall_park") and os.environ.get("AMC_TEMP_NO_PARK") != "1"
+    force_redo = os.environ.get("AMC_TEMP_FORCE_GAP_REDO") == "1"       # (tests: take the finish-first path at the next case with hits)
     if getattr(hooks, "early_gap", False) and hasattr(energies, "gap_start"):
         e_idx, _, e_cz, e_ok = hooks.wall_hits(GAP_CASE)
         if len(e_idx):
             h = energies.gap_start(np.asarray(e_cz)[np.flatnonzero(np.asarray(e_ok))].tolist())
             if h is not None:
                 early = (np.array(e_idx), np.array(e_cz), np.array(e_ok), h)
+    parked = None                               # (idx, good, energy handle or contact heights)
+
+    def finish_parked():
+        nonlocal parked
+        p_idx, p_good, p_src = parked
+        Es = np.zeros(len(p_idx))
+        Es[p_good] = energies.gap_finish(p_src) if isinstance(p_src, tuple) else energies.gap_many(p_src)
+        dpz, _ = hooks.wall_finish(GAP_CASE, Es)
+        part[GAP_CASE] = (sequential_sum(np.asarray(dpz, dtype=np.float64)[p_good].tolist()), None, len(p_good) > 0)
+        parked = None
+
     with (sampler.session() if hasattr(sampler, "session") else _NoSession(sampler)):
         for case in CASES:
             idx, normals, contact_z, ok = hooks.wall_hits(case)
             n = len(idx)
+            if parked is not None and n and (force_redo or np.intersect1d(parked[0], idx).size):
+                # a later case hits a parked particle: its contact solve needs the velocity the gap case gives it
+                force_redo = False
+                finish_parked()
+                hooks.wall_hits_again()
+                idx, normals, contact_z, ok = hooks.wall_hits(case)
+                n = len(idx)
             if n == 0:
                 if case == GAP_CASE and early is not None:
                     energies.gap_finish(early[3])           # (drain the workers' answers: nothing hit after all)
@@ -568,16 +594,25 @@ def drive_energised_cases(hooks, sampler, energies):
                         dirs[k] = sampler.random_inbounds_direction(np.array(normals[k]))
             good = np.flatnonzero(np.asarray(ok))
             Es = np.zeros(n)
-            if case == GAP_CASE and early is not None:
-                e_vals = energies.gap_finish(early[3])
-                if np.array_equal(early[0], idx) and np.array_equal(early[1], contact_z) and np.array_equal(early[2], ok):
-                    Es[good] = e_vals
-                else:
-                    Es[good] = energies.gap_many(np.asarray(contact_z)[good].tolist())
-                early = None
-            elif case == GAP_CASE:
-                if hasattr(energies, "gap_many"):
-                    Es[good] = energies.gap_many(np.asarray(contact_z)[good].tolist())
+            if case == GAP_CASE:
+                src = None                                  # the energies: an early handle that matches, or still to be computed
+                if early is not None:
+                    if np.array_equal(early[0], idx) and np.array_equal(early[1], contact_z) and np.array_equal(early[2], ok):
+                        src = early[3]
+                    else:
+                        energies.gap_finish(early[3])       # (discarded)
+                    early = None
+                zs = np.asarray(contact_z)[good].tolist()
+                if can_park:
+                    if src is None and hasattr(energies, "gap_start"):
+                        src = energies.gap_start(zs)
+                    hooks.wall_park(case, dirs)
+                    parked = (np.array(idx), good, src if src is not None else zs)
+                    continue
+                if src is not None:
+                    Es[good] = energies.gap_finish(src)
+                elif hasattr(energies, "gap_many"):
+                    Es[good] = energies.gap_many(zs)
                 else:
                     for k in good:
                         Es[k] = energies.gap(contact_z[k])
@@ -586,14 +621,24 @@ def drive_energised_cases(hooks, sampler, energies):
             dpz, dE = hooks.wall_apply(case, dirs, Es)
             # (left-to-right sums over plain Python floats: the same additions in the same order as the reference's loop)
             m_case = sequential_sum(np.asarray(dpz, dtype=np.float64)[good].tolist())
-            mom = mom + m_case
-            had_m = had_m or len(good) > 0
-            if case in COLD_CASES:
-                cold = cold + sequential_sum(np.asarray(dE, dtype=np.float64)[good].tolist())
-                had_c = had_c or len(good) > 0
-            elif case in HOT_CASES:
-                hot = hot + sequential_sum(np.asarray(dE, dtype=np.float64)[good].tolist())
-                had_h = had_h or len(good) > 0
+            e_case = None if case == GAP_CASE else sequential_sum(np.asarray(dE, dtype=np.float64)[good].tolist())
+            part[case] = (m_case, e_case, len(good) > 0)
+        if parked is not None:
+            finish_parked()
+    mom = cold = hot = 0
+    had_m = had_c = had_h = False
+    for case in CASES:
+        if case not in part:
+            continue
+        m_case, e_case, any_good = part[case]
+        mom = mom + m_case
+        had_m = had_m or any_good
+        if case in COLD_CASES:
+            cold = cold + e_case
+            had_c = had_c or any_good
+        elif case in HOT_CASES:
+            hot = hot + e_case
+            had_h = had_h or any_good
     return mom, cold, hot, had_m, had_c, had_h
 
 

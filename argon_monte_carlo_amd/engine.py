@@ -267,6 +267,22 @@ class EnergisedEngine(Engine):
         self._ck(self.lib.amc_wall_apply(self._ctx, int(case), _d(dirs), _d(Es), n, _d(dpz), _d(dE)))
         return dpz[:n], dE[:n]
 
+    # a case parked while its surface energies are still being integrated (energised.drive_energised_cases)
+    def wall_park(self, case, dirs):
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        self._ck(self.lib.amc_wall_park(self._ctx, int(case), _d(dirs), len(dirs)))
+
+    def wall_finish(self, case, Es):
+        Es = np.ascontiguousarray(Es, dtype=np.float64)
+        n = len(Es)
+        dpz = np.zeros(max(1, n))
+        dE = np.zeros(max(1, n))
+        self._ck(self.lib.amc_wall_finish(self._ctx, int(case), _d(Es), n, _d(dpz), _d(dE)))
+        return dpz[:n], dE[:n]
+
+    def wall_hits_again(self):
+        self._ck(self.lib.amc_wall_hits_again(self._ctx))
+
     def temp_end(self):
         st = AmcStepStats()
         self._ck(self.lib.amc_temp_end(self._ctx, C.byref(st)))

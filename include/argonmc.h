@@ -210,6 +210,15 @@ int amc_wall_hits(amc_ctx *ctx, int case_id, int32_t *idx, double *normal_xyz, d
  * per-hit z-momentum and energy changes (Temp:384-389), which the caller sums left to right like the reference. */
 int amc_wall_apply(amc_ctx *ctx, int case_id, const double *dir_xyz, const double *surface_energy, size_t n,
                    double *dpz, double *dE);
+/* A case whose surface energies are still being computed (the gap case: mpmath.quad per hit, Temp:143-152, in worker
+ * processes) can be PARKED: amc_wall_park does everything of amc_wall_apply that does not depend on the energy (completed
+ * path, counters, particle at its contact point — what the following cases' masks read), amc_wall_finish sets the new
+ * velocities and returns the per-hit changes once the energies are there.  Exact as long as no later case of the step hits
+ * a parked particle in between: the caller compares the hit lists, finishes first if one does and calls
+ * amc_wall_hits_again so that the next amc_wall_hits evaluates its case anew on the finished state. */
+int amc_wall_park(amc_ctx *ctx, int case_id, const double *dir_xyz, size_t n);
+int amc_wall_finish(amc_ctx *ctx, int case_id, const double *surface_energy, size_t n, double *dpz, double *dE);
+int amc_wall_hits_again(amc_ctx *ctx);
 /* recapture (Temp:804) -> p-p sweep (Temp:813-842) -> recapture (Temp:844); returns the step's counters */
 int amc_temp_end(amc_ctx *ctx, amc_step_stats *out);
 

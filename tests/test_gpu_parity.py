@@ -435,6 +435,55 @@ def test_temp_two_steps_vs_oracle(O, n):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["park", "force_redo", "no_park", "no_workers"])
+def test_gap_case_parked_and_finished_later_equals_oracle(O, monkeypatch, mode):
+    """The gap case's integrals start ahead of case 3 and the case is PARKED at its turn and finished after case 9
+    (energised.drive_energised_cases).  N = 1,000,000 has about five gap hits per step: three steps == oracle bit for bit,
+    incl. the step's momentum / energy sums, (a) as is, (b) with the finish-first path forced (what happens when a later
+    case hits a parked particle), (c) without parking, (d) without worker processes."""
+    import random
+    from argon_monte_carlo_amd.energised import DirectionSampler, SurfaceEnergies
+    from argon_monte_carlo_amd.engine import EnergisedEngine
+    if mode == "force_redo":
+        monkeypatch.setenv("AMC_TEMP_FORCE_GAP_REDO", "1")
+    if mode == "no_park":
+        monkeypatch.setenv("AMC_TEMP_NO_PARK", "1")
+    if mode == "no_workers":
+        monkeypatch.setenv("AMC_GAP_WORKERS", "0")
+    p, c = PR.pore_params(n=1_000_000, energised=True)
+    p.reserved0 |= 1
+    init = IC.pore_ic(p, c, seed=17)
+    energies = SurfaceEnergies(c)
+    eng = EnergisedEngine(p)
+    calls = {"park": 0, "finish": 0, "again": 0}
+    for name in ("park", "finish"):
+        orig = getattr(eng, "wall_" + name)
+        setattr(eng, "wall_" + name, (lambda f, k: (lambda *a: (calls.__setitem__(k, calls[k] + 1), f(*a))[1]))(orig, name))
+    orig_again = eng.wall_hits_again
+    eng.wall_hits_again = lambda: (calls.__setitem__("again", calls["again"] + 1), orig_again())[1]
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 16)
+    eng.upload(*init); orc.upload(*init)
+    s_dev = DirectionSampler(np.random.RandomState(17), random.Random(17))
+    s_orc = DirectionSampler(np.random.RandomState(17), random.Random(17))
+    try:
+        for s in range(3):
+            st, m, ec, eh, hm, hc, hh = eng.temp_timestep(c["dt"], s_dev, energies)
+            rc, so, m2, ec2, eh2, hm2, hc2, hh2 = orc.temp_timestep(c["dt"], s_orc, energies)
+            assert rc == 0
+            for k in ("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"):
+                assert st[k] == so[k], (mode, s, k, st, so)
+            assert (m, ec, eh, hm, hc, hh) == (m2, ec2, eh2, hm2, hc2, hh2), (mode, s)
+            assert_state_equal(eng.download(), orc.state(), ("gap", mode, s))
+    finally:
+        SurfaceEnergies._shutdown_pool()
+    if mode == "no_park":
+        assert calls["park"] == 0
+    else:
+        assert calls["park"] == calls["finish"] >= 2, calls         # (a step without a gap hit parks nothing)
+    assert (calls["again"] >= 1) == (mode == "force_redo"), calls
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------- edge cases
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 17])
 @pytest.mark.parametrize("kind", ["cube", "pore"])
