@@ -141,6 +141,7 @@ int amc_wall_park(amc_ctx *c, int case_id, const double *dir_xyz, size_t n)
         return amc_fail(c, AMC_ERR_STATE, "amc_wall_park(case %d, n=%zu) does not match the pending amc_wall_hits(case %d, n=%d)", case_id, n, T.last_case, T.last_n);
     if (T.def_case >= 0) return amc_fail(c, AMC_ERR_STATE, "amc_wall_park: case %d is still parked", T.def_case);
     T.last_case = -1;
+    T.def_case = case_id; T.def_n = 0;          // (a shard without a hit of its own parks nothing and finishes nothing)
     if (n == 0) return AMC_OK;
     if (!dir_xyz) return AMC_ERR_INVALID;
     for (size_t s = 0; s < n; s++) {

@@ -231,6 +231,22 @@ class _GlobalWallHooks:
 
     def __init__(self, engine, comm, rank):
         self.e, self.comm, self.rank = engine, comm, rank
+        # the gap case parked at its turn and finished after the last case (energised.drive_energised_cases), when the engine can
+        if hasattr(engine, "wall_park"):
+            self.early_gap = True
+            self.wall_park, self.wall_finish, self.wall_hits_again = self._wall_park, self._wall_finish, engine.wall_hits_again
+
+    def _wall_park(self, case, dirs):
+        self._parked = (self._off, self._cnt)
+        a, b = self._off, self._off + self._cnt
+        self.e.wall_park(case, np.asarray(dirs)[a:b])
+
+    def _wall_finish(self, case, Es):
+        a, b = self._parked[0], self._parked[0] + self._parked[1]
+        dpz, dE = self.e.wall_finish(case, np.asarray(Es)[a:b])
+        parts = self.comm.allgather_var(np.column_stack([dpz, dE]).reshape(-1, 2))
+        allr = np.concatenate(parts)
+        return allr[:, 0].copy(), allr[:, 1].copy()
 
     def wall_hits(self, case):
         idx, normals, contact_z, ok = self.e.wall_hits(case)

@@ -229,7 +229,7 @@ def extra_workload(name, steps, warmup, device, stream_ptr, sync):
            "pair_sweep_frac": rep.get("pair_sweep", {}).get("frac"),
            "streaming_pass_frac": rep.get("streaming_pass", {}).get("frac"),
            "per_kernel_avg_us": rep["per_kernel_avg_us"], "per_kernel_avg_launch_us": rep["per_kernel_avg_launch_us"]}
-    del eng
+    eng.close()
     return out
 
 
