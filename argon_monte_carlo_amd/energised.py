@@ -287,7 +287,14 @@ class SurfaceEnergies:
             cores = len(os.sched_getaffinity(0))
         except AttributeError:
             cores = os.cpu_count() or 1
-        return min(8, cores - 1) if cores > 2 else 0
+        try:                                        # (a container's CPU quota: a GPU box shows all of its cores to every job)
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                cores = min(cores, max(1, int(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+        # (one integral per worker at a time: a step at N = 4e6 has about twenty gap hits, a 16-core share serves them in two rounds)
+        return min(16, cores - 1) if cores > 2 else 0
 
     def _get_pool(self):
         cls = SurfaceEnergies
