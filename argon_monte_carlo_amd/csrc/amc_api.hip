@@ -964,6 +964,8 @@ int amc_kernel_times(amc_ctx *c, double *total_ms, int64_t *launches)
             static const char *pn[12] = {"graph", "walk", "reserve", "small: after emulate", "pair emulate | by the wave: emulate", "publish", "grid probe", "first hop", "particles", "set-up", "overlay probe", "small: prepare"};
             fprintf(stderr, "[amc k_clusters_wide] working waves %lld in %lld launches; launch span (first working wave in -> last out) %.2f us, last out -> ordered workgroup in %.2f us, longest wave ever %.2f us\n",
                     s[3], h[25], h[27] / nl / 100.0, h[26] / nl / 100.0, longest / 100.0);
+            fprintf(stderr, "[three-particle path of lane 0] %lld times, %lld continued from the pair's hit; loads + slots %.2f us, emulation %.2f us\n", s[5], s[6],
+                    s[7] / (double)std::max<long long>(1, s[5]) / 100.0, s[124] / (double)std::max<long long>(1, s[5]) / 100.0);
             fprintf(stderr, "[pair-wave lifetimes, 2.5 us buckets]");
             for (int k = 0; k < 8; k++) fprintf(stderr, " %lld", s[24 + k]);
             fprintf(stderr, "\n");

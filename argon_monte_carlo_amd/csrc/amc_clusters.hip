@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
     // speculative: record and state of my first candidate (valid memory for any k below the capacity)
     const int k_first = wave_id * per + lane;
     int4 c4_first = make_int4(0, 0, -1, -1);
-    unsigned int mark_first = 0;
+    unsigned long long mark_first = 0;
     if (lane < per && k_first < W.max_cand) { c4_first = W.cand4[k_first]; mark_first = W.cand_mark[k_first]; }
     int ncand = (int)A.O.cnt->cand_count;
     if (ncand > W.max_cand) ncand = W.max_cand;
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
     const bool timed__ = DBG && dbg__ && lane == 0 && wave_id * per < ncand;     // waves with work in their first pass
     if (DBG && dbg__) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CW_STAMP(7); }      // entry -> candidate count and my first candidate have arrived
     int cat__ = 0;
+    long long d_cont = 0, d_three = 0, d_t_load = 0, d_t_emu = 0;      // (diagnostic: the three-particle path of lane 0)
     for (int k0 = wave_id * per; k0 < ncand; k0 += nwaves * per) {       // wave-uniform trip count
         const int k = k0 + lane;
         const bool valid = lane < per && k < ncand;
@@ -288,14 +289,27 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         int4 c4 = make_int4(0, 0, -1, -1);
         int head_i = -1, head_j = -1;
         amc_particle pre_j, pre_i;          // state of both particles
+        bool fh_ok = false;                 // a pair's only hit can be taken over when its validation pulls a third particle in
+        int fh_it0 = -1, fh_pj = -1, fh_pi = -1, fh_sj = -1, fh_si = -1;
         bool iso = false;
+        // a chain of two candidates (k, then k2 on one of my particles, nothing else anywhere): the second candidate
+        // comes with my mark, so the component is known after ONE round trip (its record and its mark)
+        int k2 = -1;
+        int4 c4b = make_int4(0, 0, -1, -1);
+        unsigned long long mkb = 0;
         if (valid) {
             c4 = (k == k_first) ? c4_first : W.cand4[k];
-            const unsigned int mk = (k == k_first) ? mark_first : W.cand_mark[k];
+            const unsigned long long mk = (k == k_first) ? mark_first : W.cand_mark[k];
+            const bool marked = (unsigned int)(mk >> 32) == A.sweep_epoch;
             // alone on both particles: nobody before it in either list, nobody displaced it from either head (the detect
             // kernel marks the displaced candidate) — decided from candidate-indexed words only
-            iso = c4.z < 0 && c4.w < 0 && mk != A.sweep_epoch;
-            if (!iso) {                     // part of a larger component: the walk below starts at the particles' heads
+            iso = c4.z < 0 && c4.w < 0 && !marked;
+            if (c4.z < 0 && c4.w < 0 && marked) {
+                const unsigned int succ = (unsigned int)(mk & 0xffffffffULL);
+                if (succ != AMC_MARK_MULTI && (int)succ > k && (int)succ < ncand) k2 = (int)succ;
+            }
+            if (k2 >= 0) { c4b = W.cand4[k2]; mkb = W.cand_mark[k2]; }
+            else if (!iso) {                // part of a larger component: the walk below starts at the particles' heads
                 head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
                 head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
             }
@@ -311,7 +325,19 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         int nm = 2, nc = 1;
         int *mem = L.mem[lane], *cnd = L.cnd[lane];
         mem[0] = c4.y; mem[1] = c4.x; cnd[0] = k;
-        if (owner) {
+        bool chain2 = false;
+        if (k2 >= 0) {
+            // k2 is the head of both its particles' lists (nobody displaced it), my candidate is the one before it on the
+            // shared particle and there is nobody before it on the other: the component is {k, k2}, three particles
+            const bool via_x = c4b.z == k && c4b.w < 0, via_y = c4b.w == k && c4b.z < 0;
+            chain2 = (unsigned int)(mkb >> 32) != A.sweep_epoch && (via_x || via_y);
+            if (chain2) { mem[2] = via_x ? c4b.y : c4b.x; cnd[1] = k2; nm = 3; nc = 2; }
+            else {                          // something else: the general walk, from the heads
+                head_i = cw_adj_head(W, A.sweep_epoch, c4.x);
+                head_j = cw_adj_head(W, A.sweep_epoch, c4.y);
+            }
+        }
+        if (owner && !chain2) {
             for (int cur = 0; cur < nm && owner; cur++) {
                 const int p = mem[cur];
                 int c = cur == 0 ? head_j : (cur == 1 ? head_i : cw_adj_head(W, A.sweep_epoch, p));
@@ -335,14 +361,14 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
                     c = nx;
                 }
             }
-            if (owner)                                              // members in ascending particle index (Pore:538)
-                for (int a = 1; a < nm; a++) {
-                    const int v = mem[a];
-                    int b = a - 1;
-                    while (b >= 0 && mem[b] > v) { mem[b + 1] = mem[b]; b--; }
-                    mem[b + 1] = v;
-                }
         }
+        if (owner)                                                  // members in ascending particle index (Pore:538)
+            for (int a = 1; a < nm; a++) {
+                const int v = mem[a];
+                int b = a - 1;
+                while (b >= 0 && mem[b] > v) { mem[b + 1] = mem[b]; b--; }
+                mem[b + 1] = v;
+            }
         CW_STAMP(1);
         // ---- 2. no allocation: member t of a cluster takes slot 2 c + (t & 1) of the cluster's candidate c = cnd[t / 2]
         // (a cluster of nc candidates has at most nc + 1 particles), the q-th hit the history pair of candidate cnd[q] ----
@@ -377,28 +403,53 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
                     cw_init_slot(W, si, pi, lab, g + 1, true);
                     W.cand_s[k] = make_int4(si, sj, 1, 0);
                     CW_STAMP(11);
-                    rs_emulate_pair<GEOM>(A, wc, pre_j, pre_i, pj, pi, sj, si, &wd);
+                    amc_particle p1 = pre_j, p2 = pre_i;
+                    const bool mv = rs_emulate_pair_io<GEOM>(A, wc, p1, p2, pj, pi, sj, si, &wd);
+                    // exactly one hit, and it moved the pair (their state after it is in their slots)
+                    fh_ok = mv && L.used[lane] == 1 && !L.unv[lane] && GEOM != AMC_GEOM_CELL;
+                    fh_pj = pj; fh_pi = pi; fh_sj = sj; fh_si = si;
+                    fh_it0 = L.it0[lane];
                     CW_STAMP(4);
+                    L.gen[lane] = g + 1;
                 } else {
+                    // A pair that pulled ONE particle in continues from its hit (rs_first_hit) under the round tag it has: the
+                    // hit's entries, events and work items stay valid (their positions have been probed against the grid
+                    // already), only the new member gets a slot.  Anything else starts over under the next tag.
+                    const bool cont = fh_ok && g == 1;
+                    fh_ok = false;
+                    const long long d_t0 = timed__ ? wall_clock64() : 0;
                     amc_particle q[3];
                     int pidx[3], slot[3];
                     bool moved[3] = {false, false, false};
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
                         pidx[a] = mem[a]; slot[a] = L.msl[lane][a];
-                        q[a] = rs_load_particle(A.S, pidx[a]);
+                        // (first emulation: the candidate's two particles were loaded with it)
+                        if (g == 0 && pidx[a] == c4.y) q[a] = pre_j;
+                        else if (g == 0 && pidx[a] == c4.x) q[a] = pre_i;
+                        else q[a] = rs_load_particle(A.S, pidx[a]);
                     }
+                    rs_first_hit fh;
+                    fh.pj = cont ? fh_pj : -1; fh.pi = cont ? fh_pi : -1;
+                    if (cont) { fh.p1 = rs_load_slot(W, fh_sj); fh.p2 = rs_load_slot(W, fh_si); }
+                    else { fh.p1 = q[0]; fh.p2 = q[0]; }
+                    const int tag = cont ? g : g + 1;
 #pragma unroll
-                    for (int a = 0; a < 3; a++) cw_init_slot(W, slot[a], pidx[a], lab, g + 1);
+                    for (int a = 0; a < 3; a++)
+                        if (!cont || (pidx[a] != fh_pj && pidx[a] != fh_pi)) cw_init_slot(W, slot[a], pidx[a], lab, tag);
+                    if (cont) { wd.gen = tag; L.used[lane] = 1; L.it0[lane] = fh_it0; }
                     if (g == 0)
                         for (int e = 0; e < L.nc[lane]; e++) cw_candidate_slots(W, L, lane, e);
-                    rs_emulate_small<GEOM, 3>(A, wc, q, pidx, slot, moved, &wd);
+                    long long d_t1 = 0;
+                    if (DBG && timed__) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); d_t1 = wall_clock64(); }
+                    rs_emulate_small<GEOM, 3>(A, wc, q, pidx, slot, moved, &wd, cont, fh);
+                    if (DBG && timed__) { d_three++; d_cont += cont; d_t_load += d_t1 - d_t0; d_t_emu += wall_clock64() - d_t1; }
 #pragma unroll
                     for (int a = 0; a < 3; a++)
                         if (moved[a]) rs_store_slot(W, slot[a], q[a]);
+                    L.gen[lane] = tag;
                 }
                 if (L.unv[lane]) rs_add_edge(W, wc, mem[0], mem[0]);     // (self edge: the ordered workgroup redoes this cluster)
-                L.gen[lane] = g + 1;
                 L.redo[lane] = 0;
             }
             // (a cluster whose pulled particle did not fit goes through the cooperative path below all the same: its members,
@@ -522,6 +573,7 @@ __global__ __launch_bounds__(64 * CW_WPB) void k_clusters_wide(rs_args A_in_kern
         R[0] = t_enter__; R[1] = t_exit; R[2] = A.sweep_epoch;          // (this launch: the ordered workgroup forms the span)
         R[3] += 1;
         if (life > R[4]) R[4] = life;
+        R[5] += d_three; R[6] += d_cont; R[7] += d_t_load; R[124] += d_t_emu;   // (R[124..127]: the tail of the last category's figures, never reached)
         R[8 + cat__] += life; R[16 + cat__] += 1;                       // by kind of wave
         for (int e = 0; e < 12; e++) R[32 + 12 * cat__ + e] += t_acc[e];
         if (cat__ == 0) { int bk = (int)(life / 250); if (bk > 7) bk = 7; R[24 + bk] += 1; }

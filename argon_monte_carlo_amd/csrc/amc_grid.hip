@@ -54,7 +54,7 @@ struct amc_adj {
     int4 *sl_meta;
     int *sl_hits, *ev_gen;
     unsigned int epoch;
-    unsigned int *mark;
+    unsigned long long *mark;
 };
 
 AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt, const amc_adj &D)
@@ -72,8 +72,14 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
             // the candidates my exchanges displaced are no longer alone on their particle: told in a candidate-indexed word,
             // so that the lane of an ISOLATED pair (99 %) never has to read the particle-indexed heads (a sparsely touched
             // N-sized array: its translation misses made that one load 4.3 us of the wide kernel's 12 us chain)
-            if (r.z >= 0) D.mark[r.z] = D.epoch;
-            if (r.w >= 0) D.mark[r.w] = D.epoch;
+            // The word also names the displacing candidate (its SUCCESSOR in that particle's list), so that the owner of a
+            // two-candidate chain reaches the second candidate in one hop; a candidate displaced on both particles only says so.
+            auto mark = [&](int kd) {
+                const unsigned long long old = atomicExch(&D.mark[kd], mine);
+                if ((unsigned int)(old >> 32) == D.epoch) D.mark[kd] = ((unsigned long long)D.epoch << 32) | AMC_MARK_MULTI;
+            };
+            if (r.z >= 0) mark(r.z);
+            if (r.w >= 0) mark(r.w);
         }
         D.rec[k] = r;
         D.sd[k] = make_int4(-1, -1, 0, 0);      // (slot of i, slot of j, done by the wide kernel, -)
@@ -157,7 +163,13 @@ AMC_DEV void amc_detect_node(const amc_grid &G, const amc_lists &B, int node, do
 
 // One thread per particle; in an overlapped run (amc_stream.hip) a few more blocks take the extra nodes (amc_lists), whose
 // number only the device knows.
-__global__ __launch_bounds__(256) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
+#ifndef AMC_DETECT_MINW
+#define AMC_DETECT_MINW 4       // waves per SIMD the register allocation has to leave room for (128 registers): at 129 the
+                                // kernel ran with three and took 22 % longer in the pore at N = 1e6.  Measured beside it: 5 and
+                                // 6 waves bought with spills (96 / 80 registers) 36.0 / 42.4 us against 35.9; the candidate push
+                                // as a real call instead of inlined (116 registers, but the call's frame) 48 us
+#endif
+__global__ __launch_bounds__(256, AMC_DETECT_MINW) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
                                                       int max_cand, amc_dev_counters *cnt, amc_adj D, const int *extra_count,
                                                       int max_extra)
 {

@@ -46,6 +46,7 @@ struct amc_rec {
     float x, y, z;
     int next;
 };
+#define AMC_MARK_MULTI 0xffffffffu
 struct amc_lists {
     unsigned long long *head; // [ncells]
     amc_rec *rec;             // [n + max_extra]: list NODES.  Node p < n is particle p.  Nodes n + e are handed out by the fix-up
@@ -96,8 +97,9 @@ struct amc_resolve_ws {
     // candidates: cand4[k] = (i, j, next candidate in i's list, next candidate in j's list), i > j (particle indices);
     // cand_s[k] = (slot of i, slot of j, done by the wide kernel, -)
     int4 *cand4, *cand_s;
-    unsigned int *cand_mark;  // [max_cand] == sweep epoch: a later candidate of this sweep shares a particle with this one (set by the
-                              // detect kernel when its exchange on the particle's graph head returns this candidate)
+    unsigned long long *cand_mark;  // [max_cand] (sweep epoch << 32) | successor: a later candidate of this sweep shares a particle with
+                              // this one — the candidate whose exchange on the particle's graph head returned this one (detect
+                              // kernel); AMC_MARK_MULTI in the low half when that happened on both of its particles
     int max_cand;
     unsigned long long *adj_head;   // [n] (sweep epoch << 32) | last candidate pushed that touches the particle
     int *slot_of;             // [n] particle -> slot or -1

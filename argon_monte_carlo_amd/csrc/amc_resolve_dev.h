@@ -89,6 +89,14 @@ AMC_DEV void rs_store_slot(const amc_resolve_ws &W, int s, const amc_particle &q
     t[6] = q.d; t[7] = q.dx; t[8] = q.dy; t[9] = q.dz; t[10] = q.flag ? 1.0 : 0.0;
     W.sl_moved[s] = 1;
 }
+AMC_DEV amc_particle rs_load_slot(const amc_resolve_ws &W, int s)
+{
+    const double *t = W.sl_state + (size_t)s * RS_SLOT_DOUBLES;
+    amc_particle q;
+    q.x = t[0]; q.y = t[1]; q.z = t[2]; q.vx = t[3]; q.vy = t[4]; q.vz = t[5];
+    q.d = t[6]; q.dx = t[7]; q.dy = t[8]; q.dz = t[9]; q.flag = t[10] != 0.0;
+    return q;
+}
 // scratch state of a slot -> the particle arrays (commit)
 AMC_DEV void rs_apply_slot(const amc_resolve_ws &W, const amc_state &S, int s, int p)
 {
@@ -323,9 +331,10 @@ AMC_DEV int rs_next_common(double v1, double v2, double d, double inv_d, double 
 }
 
 // ---- two-particle cluster: literal emulation with both particles in registers -----------------------------------------
+// (in / out form: p1, p2 come back as the emulation left them; returns whether anything moved)
 template <int GEOM>
-AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, amc_particle p2, int pj, int pi, int sj, int si,
-                             rs_wide *wd = nullptr)
+AMC_DEV bool rs_emulate_pair_io(const rs_args &A, rs_shared *sh, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj, int si,
+                                rs_wide *wd = nullptr)
 {
     const rs_geom &P = A.P;
     bool moved = false;
@@ -387,6 +396,35 @@ AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, a
         rs_store_slot(A.W, sj, p1);
         rs_store_slot(A.W, si, p2);
     }
+    return moved;
+}
+template <int GEOM>
+AMC_DEV void rs_emulate_pair(const rs_args &A, rs_shared *sh, amc_particle p1, amc_particle p2, int pj, int pi, int sj, int si,
+                             rs_wide *wd = nullptr)
+{
+    rs_emulate_pair_io<GEOM>(A, sh, p1, p2, pj, pi, sj, si, wd);
+}
+
+// The first hit of a cluster's emulation when it is already known (k_clusters_wide: a pair that was emulated, published
+// nothing yet, and then pulled a third particle in).  The pulled-in particle overlapped nobody before that hit — it was in
+// no candidate — and layers / colour groups are searched for OVERLAPPING pairs only, so the grown cluster's emulation
+// reaches the pair's first hit in the same cell with the same operands: its result is installed instead of computed again
+// (history entries, events and the hit count of that hit stay as the pair's emulation left them, same round tag).
+struct rs_first_hit {
+    int pj, pi;                 // the pair (j < i)
+    amc_particle p1, p2;        // their state after the hit
+};
+
+template <int GEOM, int M>
+AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)[M], const int (&pidx)[M],
+                              const int (&slot)[M], bool (&moved)[M], rs_wide *wd, bool known, const rs_first_hit &fh);
+template <int GEOM, int M>
+AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)[M], const int (&pidx)[M],
+                              const int (&slot)[M], bool (&moved)[M], rs_wide *wd)
+{
+    rs_first_hit none;
+    none.pj = none.pi = -1; none.p1 = q[0]; none.p2 = q[0];
+    rs_emulate_small<GEOM, M>(A, sh, q, pidx, slot, moved, wd, false, none);
 }
 
 // ---- small cluster (M = 3 or 4 members), all members in registers of ONE lane ----------------------------------------
@@ -416,8 +454,10 @@ AMC_DEV int rs_small_next_layer(const double (&v)[M], const bool (&ok)[M], const
 
 template <int GEOM, int M>
 AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)[M], const int (&pidx)[M],
-                              const int (&slot)[M], bool (&moved)[M], rs_wide *wd)
+                              const int (&slot)[M], bool (&moved)[M], rs_wide *wd, bool known, const rs_first_hit &fh)
 {
+    // (known: the first hit is fh — handed over by reference and a flag, not by a pointer that may be null: the structure
+    // has to stay in registers)
     const rs_geom &P = A.P;
     const double cr = P.collision_range;
     bool ovp[M][M];                     // ovp[c][a], c < a: the pair overlaps at the current positions
@@ -431,7 +471,11 @@ AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)
         }
     // a hit on (c0, a0): collide, then re-evaluate the pairs that contain one of the two
     auto hit = [&](int c0, int a0, amc_particle &p1, amc_particle &p2, int pj, int pi, int sj, int si, int phase, long long cell) {
-        if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, phase, cell, wd)) { moved[c0] = true; moved[a0] = true; }
+        if (known) {
+            known = false;
+            if (pj == fh.pj && pi == fh.pi) { p1 = fh.p1; p2 = fh.p2; moved[c0] = true; moved[a0] = true; }
+            else if (wd) *wd->unval = 1;            // (cannot happen, see rs_first_hit; if it did, the ordered workgroup redoes the cluster)
+        } else if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, phase, cell, wd)) { moved[c0] = true; moved[a0] = true; }
         any = false;
 #pragma unroll
         for (int a = 1; a < M; a++)
