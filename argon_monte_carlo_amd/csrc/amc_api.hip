@@ -172,7 +172,8 @@ void amc_destroy(amc_ctx *c)
     hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->s_slab, c->s_slab2, c->d_lay, c->B_buf[0].rec, c->B_buf[0].head, c->B_buf[1].rec, c->B_buf[1].head,
                     c->extra_buf[0], c->extra_count, c->wev_buf[0].rec, c->wev_buf[0].count, c->ovl_flags,
-                    c->W.ov_head, c->w_slab, c->d_rec, c->d_hist, c->d_edges, c->d_cnt, c->d_banks, c->d_dbg};
+                    c->W.ov_head, c->w_slab, c->d_rec, c->d_hist, c->d_edges, c->d_cnt, c->d_banks, c->d_dbg,
+                    c->B_buf[0].cell_of, c->B_buf[0].node_of, c->B_buf[0].bank_count, c->keep_K >= 2 ? (void *)c->B_buf[0].extra : nullptr};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -303,11 +304,41 @@ int amc_create(amc_ctx **out, const amc_params *p)
         if (!c->allpairs) {
             const size_t nc = (size_t)c->G.ncells;
             c->max_extra = AMC_EXTRA_NODES(c->n);
-            CK(dalloc(&c->B.rec, n + (size_t)c->max_extra));
+            // kept lists (amc_lists): AMC_LIST_KEEP=K, a full build every K steps.  Off in an overlapped run (its fix-up kernel
+            // files particles itself), for the energised pore (its wall cases move particles after the pass) and when the
+            // all-pairs detector is in front.
+            c->keep_K = 0; c->lists_age = -1; c->keep_threads = 0;
+            size_t pool = 0;
+            {
+                int K = (p->geometry == AMC_GEOM_PORE) ? AMC_LIST_KEEP_DEFAULT_PORE : 0;
+                if (const char *e = getenv("AMC_LIST_KEEP")) K = atoi(e);
+                if (c->overlap_mode || c->detect_ap || p->geometry == AMC_GEOM_PORE_ENERGISED || p->geometry == AMC_GEOM_CELL) K = 0;
+                const int threads = getenv("AMC_STREAM_BS") ? atoi(getenv("AMC_STREAM_BS")) : 256;
+                const long long nblocks = ((long long)n + threads - 1) / threads;
+                const long long per_bank = (nblocks + AMC_KEEP_BANKS - 1) / AMC_KEEP_BANKS;
+                // (a bank holds everything its blocks could hand out in K - 1 steps; shorter cycles rather than more than 2^30 nodes)
+                while (K >= 2 && (long long)n + per_bank * threads * (K - 1) * AMC_KEEP_BANKS > 0x3fffffffLL) K--;
+                if (K >= 2 && n > 0) {
+                    c->keep_K = K; c->keep_threads = threads;
+                    c->B.bank_cap = (int)(per_bank * threads * (K - 1));
+                    pool = (size_t)c->B.bank_cap * AMC_KEEP_BANKS;
+                }
+            }
+            CK(dalloc(&c->B.rec, n + std::max((size_t)c->max_extra, pool)));
             CK(dalloc(&c->B.head, nc + 1));
             CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
             c->B.epoch = 0;
             c->B.n = (int)c->n; c->B.extra = nullptr;
+            c->B.cell_of = c->B.node_of = c->B.bank_count = nullptr;
+            if (c->keep_K >= 2) {
+                CK(dalloc(&c->B.extra, pool));
+                CK(dalloc(&c->B.cell_of, n));
+                CK(dalloc(&c->B.node_of, n));
+                CK(dalloc(&c->B.bank_count, AMC_KEEP_BANKS));
+                CK(hipMemsetAsync(c->B.bank_count, 0, sizeof(int) * AMC_KEEP_BANKS, c->stream));
+            } else {
+                c->B.bank_cap = 0;
+            }
             c->B_buf[0] = c->B;
             CK(dalloc(&c->W.ov_head, nc));
             CK(hipMemsetAsync(c->W.ov_head, 0xff, sizeof(int) * std::max<size_t>(nc, 1), c->stream));
@@ -443,6 +474,7 @@ int amc_upload(amc_ctx *c, const double *x, const double *y, const double *z, co
     if (!c) return AMC_ERR_INVALID;
     AMC_HIP(c, hipSetDevice(c->device));
     { int rc_ = amc_flush(c); if (rc_) return rc_; }
+    c->lists_age = -1;          // (kept lists: a new state starts with a full build)
     const size_t nb = sizeof(double) * (size_t)c->n;
     const double *src[] = {x, y, z, vx, vy, vz, dist, dist_x, dist_y, dist_z};
     double *dst[] = {c->S.x, c->S.y, c->S.z, c->S.vx, c->S.vy, c->S.vz, c->S.d, c->S.dx, c->S.dy, c->S.dz};

@@ -123,6 +123,7 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
     S.pub[0] = c->kin_vpub; S.pub[1] = c->kin_vpub + c->n; S.pub[2] = c->kin_vpub + 2 * c->n;
     amc_prof_begin(c, AMC_K_BIN_COUNT);       // (the list build is what these kernels cost)
     if (!unpack) {
+        c->lists_age = -1;
         c->B.epoch++;                           // a new set of lists: this shard now, the other shards at the unpack
         c->kin_lists = true;
         if (!c->kin_counts_clear) {             // (normally the previous step's unpack kernel has cleared the banks' counters)

@@ -174,6 +174,22 @@ __global__ __launch_bounds__(256, AMC_DETECT_MINW) void k_detect_lists(amc_grid 
                                                       int max_extra)
 {
     const long long nb = (n + blockDim.x - 1) / blockDim.x;
+    if (!extra_count && (long long)gridDim.x > nb) {
+        // kept lists: AMC_KEEP_DET_J blocks per bank of extra nodes, at the FRONT of the grid (behind it they would be a tail of
+        // full-length walks after everybody else has finished)
+        const long long eb_n = (long long)gridDim.x - nb;
+        if ((long long)blockIdx.x >= eb_n) {
+            const long long p = ((long long)blockIdx.x - eb_n) * blockDim.x + threadIdx.x;
+            if (p < n) amc_detect_node(G, B, (int)p, cr2i, cr_probe, max_cand, cnt, D);
+            return;
+        }
+        const int eb = (int)blockIdx.x, bank = eb / AMC_KEEP_DET_J, j = eb % AMC_KEEP_DET_J;
+        int ne = B.bank_count[bank];
+        if (ne > B.bank_cap) ne = B.bank_cap;
+        for (int e = j * (int)blockDim.x + (int)threadIdx.x; e < ne; e += AMC_KEEP_DET_J * (int)blockDim.x)
+            amc_detect_node(G, B, (int)n + bank * B.bank_cap + e, cr2i, cr_probe, max_cand, cnt, D);
+        return;
+    }
     if ((long long)blockIdx.x < nb) {
         const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         if (p < n) amc_detect_node(G, B, (int)p, cr2i, cr_probe, max_cand, cnt, D);
@@ -296,6 +312,7 @@ hipError_t amc_launch_bin(amc_ctx *c)
     if (c->allpairs || c->n <= 0) return hipSuccess;
     const long long n = c->n;
     c->B.epoch++;
+    c->lists_age = -1;          // (kept lists: these are not the streaming pass's own)
     amc_prof_begin(c, AMC_K_BIN_COUNT);
     amc_ovl V;
     V.adj_head = nullptr; V.skip_epoch = 0;
@@ -416,12 +433,13 @@ hipError_t amc_launch_detect(amc_ctx *c)
         }
     } else {
         // (an overlapped run: four more blocks for the particles the fix-up kernel filed again under extra nodes)
-        const bool extras = c->B.extra != nullptr;
+        const bool kept = c->keep_K >= 2 && c->lists_age > 0;       // kept lists with extra nodes: blocks per bank
+        const bool extras = !kept && c->B.extra != nullptr && c->keep_K < 2;
         const int slot = (c->B.extra == c->extra_buf[1]) ? 1 : 0;
         static const int bs = getenv("AMC_DETECT_BS") ? atoi(getenv("AMC_DETECT_BS")) : 256;      // (experiments: 64 / 128 / 256)
         // (occupancy is not what bounds this kernel: capped at 4 waves per SIMD instead of 5 it takes the same 36.7 us at
         // N = 1e6, at 2 it takes 59 — it runs at the rate of its random requests)
-        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + bs - 1) / bs) + (extras ? 4u : 0u)), dim3(bs), c->G, c->B, n, cr2i,
+        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + bs - 1) / bs) + (extras ? 4u : (kept ? (unsigned)(AMC_KEEP_BANKS * AMC_KEEP_DET_J) : 0u))), dim3(bs), c->G, c->B, n, cr2i,
                    c->G.cr_probe, c->W.max_cand, c->d_cnt, D, (const int *)(extras ? c->extra_count + slot : nullptr),
                    c->max_extra);
     }

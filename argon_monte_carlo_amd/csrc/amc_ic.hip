@@ -54,6 +54,7 @@ extern "C" int amc_init_synthetic(amc_ctx *c, const amc_ic_config *cfg)
     if (!c || !cfg || cfg->struct_size != (int32_t)sizeof(amc_ic_config)) return AMC_ERR_INVALID;
     if (cfg->n_regions < 0 || cfg->n_regions > 8 || !(cfg->a_shape >= 0.0)) return amc_fail(c, AMC_ERR_INVALID, "amc_init_synthetic: bad configuration");
     if (c->n > 0xffffffffLL) return amc_fail(c, AMC_ERR_INVALID, "amc_init_synthetic: particle index exceeds the 32-bit counter word");
+    c->lists_age = -1;          // (kept lists: a new state starts with a full build)
     if (cfg->n_regions == 0 && c->P.geometry != AMC_GEOM_CUBE && c->P.geometry != AMC_GEOM_CELL)
         return amc_fail(c, AMC_ERR_INVALID, "amc_init_synthetic: this geometry needs the region table");
     for (int r = 0; r < cfg->n_regions; r++)

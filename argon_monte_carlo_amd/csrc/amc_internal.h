@@ -55,8 +55,21 @@ struct amc_lists {
                               // the particle is filed again under node n + e, extra[e] = particle
     unsigned int epoch;       // current binning epoch (>= 1)
     int n;                    // particles (nodes below n are particles themselves)
-    const int *extra;         // [max_extra] node n + e -> particle (nullptr outside an overlapped run: no such node exists)
+    int *extra;               // [max_extra] node n + e -> particle (nullptr: no such node exists)
+    // KEPT lists (amc_list_keep, amc_grid_dev.h): the lists of a full build live on for keep_K - 1 more steps.  A
+    // particle that is still in the cell it is filed under only refreshes the position in its node; one that left gives its
+    // node a position no test passes (the node stays linked: walkers pass through it) and files a NEW node n + e in its new
+    // cell — one atomic exchange for the ~6 % that change cell per step in the pore instead of one per particle.  Nodes come
+    // from AMC_KEEP_BANKS pools (bank = block of the streaming pass mod banks, one counter each, one increment per wave);
+    // a pool holds what its blocks can hand out in keep_K - 1 steps, so it cannot run out.
+    int *cell_of;             // [n] cell the particle's live node is filed under
+    int *node_of;             // [n] that node
+    int *bank_count;          // [AMC_KEEP_BANKS] nodes handed out since the last full build
+    int bank_cap;             // nodes per bank
 };
+#define AMC_LIST_KEEP_DEFAULT_PORE 0      // (switched on once measured)
+#define AMC_KEEP_BANKS 256
+#define AMC_KEEP_DET_J 8      // blocks of the detect kernel per bank of extra nodes
 #define AMC_EXTRA_NODES(n) ((int)std::min<long long>(std::max<long long>(4096, (long long)(n) / 64), 1 << 22))
 
 // What the streaming pass of an OVERLAPPED run needs beyond the plain one (amc_run): it reads the state the
@@ -195,6 +208,9 @@ struct amc_ctx {
     unsigned int ovl_tick;    // (AMC_OVERLAP_SYNC=value: hipStreamWriteValue32 / hipStreamWaitValue32 instead of event record + wait —
     int ovl_sync_values;      // ~2 us per dependency instead of ~8, tools/ubench_xstream.hip, but the resolve suffers more: DESIGN 4.2)
     int64_t ovl_steps;        // steps run overlapped so far
+    int keep_K;               // kept lists: a full build every keep_K steps (< 2: every step, the lists are not kept)
+    int lists_age;            // steps since the last full build by the streaming pass (-1: the lists are not its own)
+    int keep_threads;         // block size of the streaming pass the pools were sized for
     int overlap_mode;         // AMC_OVERLAP: 1 (default) two streams, 2 the same kernels in order on one stream (debug), 0 off
     amc_resolve_ws W;
     char *w_slab;             // the one allocation W's arrays are carved from

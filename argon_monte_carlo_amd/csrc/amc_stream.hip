@@ -181,10 +181,18 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_state S_out, am
     }
     // fused build of the detection grid's per-cell lists (amc_grid.hip): the particle's final position of this stage
     // is in registers, so no separate binning pass over the positions is needed
-    if (build_lists) {
+    // (build_lists: 1 anew every step; kept lists — 2 the full build of a cycle, which also empties the node pools, 3 a step
+    // in between)
+    if (build_lists == 1) {
         bool outside = false;
         amc_list_insert(G, B, (int)p, q.x, q.y, q.z, &outside);
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
+    } else if (build_lists) {
+        bool outside = false, overflow = false;
+        if (build_lists == 2 && threadIdx.x == 0 && blockIdx.x < AMC_KEEP_BANKS) B.bank_count[blockIdx.x] = 0;
+        amc_list_keep(G, B, (int)p, q.x, q.y, q.z, build_lists == 2, (int)(blockIdx.x & (AMC_KEEP_BANKS - 1)), &outside, &overflow);
+        if (outside) atomicOr(&O.cnt->flags, 8ULL);
+        if (overflow) atomicOr(&O.cnt->flags, 1ULL);
     }
     amc_stream_count(O, cn, bounds_slot, (int)p);
 }
@@ -313,8 +321,17 @@ amc_commit_args amc_make_commit_args(amc_ctx *c)
 
 hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot, bool fuse_bin)
 {
+    static const int threads = getenv("AMC_STREAM_BS") ? atoi(getenv("AMC_STREAM_BS")) : 256;      // (experiments: 64 / 128 / 256)
     int build = 0;
-    if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) { build = 1; c->B.epoch++; }
+    if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) {
+        if (c->keep_K >= 2 && threads == c->keep_threads && c->B.cell_of) {
+            // kept lists: a full build when the lists are not this pass's own or the cycle is over, else a step in between
+            if (c->lists_age < 0 || c->lists_age + 1 >= c->keep_K) { build = 2; c->B.epoch++; c->lists_age = 0; }
+            else { build = 3; c->lists_age++; }
+        } else {
+            build = 1; c->B.epoch++; c->lists_age = -1;
+        }
+    }
     amc_lazy L;
     memset(&L, 0, sizeof L);
     if (c->lazy_pending) {              // (a shard: its own particles here, the slots of the others are cleared by the unpack)
@@ -333,7 +350,6 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
         C.enabled = (int)extra;
         c->commit_pending = false;
     }
-    static const int threads = getenv("AMC_STREAM_BS") ? atoi(getenv("AMC_STREAM_BS")) : 256;      // (experiments: 64 / 128 / 256)
     const unsigned blocks = (unsigned)((cnt + threads - 1) / threads) + extra;
     const int kp = c->keep_prior ? 1 : 0;
     amc_ovl V;
@@ -367,6 +383,7 @@ hipError_t amc_launch_stream_ovl(amc_ctx *c, double dt, int stages, int from, un
     const int to = 1 - from;
     amc_lists &Bn = c->B_buf[to];
     Bn.epoch++;
+    c->lists_age = -1;
     amc_lazy L;
     memset(&L, 0, sizeof L);
     amc_commit_args C = amc_make_commit_args(c);

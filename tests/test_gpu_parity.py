@@ -1156,3 +1156,52 @@ def test_overlapped_run_equals_the_plain_sequence_at_size(Engine, O, monkeypatch
         rc, _ = orc.timestep(c["dt"])
         assert rc == 0
     assert_state_equal(res["1"][1], orc.state(), workload + " vs oracle")
+
+
+@pytest.mark.parametrize("kind,n,sigma_mult,keep,steps", [("pore", 60_000, 30.0, 3, 14), ("pore", 200_000, 1.0, 8, 20),
+                                                         ("cube", 30_000, 16.0, 4, 13)])
+def test_kept_lists_equal_the_oracle(Engine, O, monkeypatch, kind, n, sigma_mult, keep, steps):
+    """AMC_LIST_KEEP=K (opt-in): the per-cell lists of a full build are kept for K - 1 more steps — a particle
+    still in its cell refreshes the position in its node, one that left poisons its node and files a new one from its
+    block's pool.  Several cycles, run() and timestep() mixed (both go through the same lists), high collision rates so
+    that clusters, pulled-in particles and validation walk lists full of dead nodes: state, counters and completed paths
+    equal the oracle's bit for bit at every step."""
+    monkeypatch.setenv("AMC_LIST_KEEP", str(keep))
+    sigma = 3.6e-19 * sigma_mult
+    if kind == "cube":
+        p, c = PR.cube_params_for_n(n, sigma=sigma)
+        init = IC.cube_ic(p, c, seed=43)
+    else:
+        p, c = PR.pore_params(n=n, sigma=sigma)
+        init = IC.pore_ic(p, c, seed=43)
+    p.detect_mode = 1
+    p.reserved1 = 1
+    eng = Engine(p)
+    orc = O.Oracle(p, mode="mul", path_capacity=1 << 22)
+    eng.upload(*init)
+    orc.upload(*init)
+    npp = 0
+    s = 0
+    while s < steps:
+        k = 3 if s % 5 == 2 else 1                  # (a run of three steps now and then: the cycle goes on across calls)
+        st = eng.run(c["dt"], k) if k > 1 else eng.timestep(c["dt"])
+        so = None
+        tot = dict.fromkeys(("n_pp", "n_wall", "n_oob_walls", "n_oob_pp", "n_paths", "n_fp_errors"), 0)
+        for _ in range(k):
+            rc, so = orc.timestep(c["dt"])
+            assert rc == 0
+            for key in tot:
+                tot[key] += so[key]
+        for key in tot:
+            assert st[key] == tot[key], (kind, s, key, st, tot)
+        npp += st["n_pp"]
+        s += k
+        assert_state_equal(eng.download(), orc.state(), ("kept lists", kind, keep, s))
+    assert npp > 0
+    # an upload starts a new cycle (full build), and the context goes on
+    eng.upload(*init)
+    orc.upload(*init)
+    eng.timestep(c["dt"])
+    orc.timestep(c["dt"])
+    assert_state_equal(eng.download(), orc.state(), ("kept lists after upload", kind))
+    eng.close()
