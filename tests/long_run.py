@@ -50,7 +50,7 @@ out = {"workload": workload, "n": int(p.n), "steps": steps, "gpu_seconds": round
 out["ok"] = bool(out["kinetic_energy_relative_drift"] < 1e-9 and outside == 0 and npaths == tot["n_paths"] and
                  tot["flags"] == 0 and out["all_finite"] and out["histogram_rows_le_total"])
 os.makedirs("gpurun_out", exist_ok=True)
-with open(f"gpurun_out/long_{workload}_{steps}" + ("_overlap" if out["overlapped_run"]["steps"] else "") + ".json", "w") as f:
+with open(f"gpurun_out/long_{workload}_{steps}" + ("_overlap" if out["overlapped_run"]["steps"] else "") + (("_keep" + os.environ["AMC_LIST_KEEP"]) if os.environ.get("AMC_LIST_KEEP", "0") not in ("", "0", "1") else "") + ".json", "w") as f:
     f.write(json.dumps(out) + "\n")
 print(json.dumps(out))
 sys.exit(0 if out["ok"] else 1)
