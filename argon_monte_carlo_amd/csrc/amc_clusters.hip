@@ -10,7 +10,9 @@
 //   1. one lane per candidate k.  It reads the candidate record (i, j, the candidates before it in the lists of i and j)
 //      and the candidate-indexed mark the detect kernel sets when a LATER candidate shares a particle with it
 //      (amc_push_candidate, amc_grid.hip).  Nobody before, nobody after  =>  isolated pair: the lane owns it and never
-//      touches the particle-indexed graph heads.  Otherwise the lane walks the component from the heads; it gives up as
+//      touches the particle-indexed graph heads.  Nobody before and ONE candidate after (the mark names it): one more
+//      record and its mark tell whether the component is that chain of two — three particles, known after one round
+//      trip.  Otherwise the lane walks the component from the heads; it gives up as
 //      soon as it meets a candidate with a lower index (the lowest candidate's lane owns the component) or when the
 //      component exceeds CW_MAXM particles / CW_MAXC candidates (left to the ordered workgroup: nobody marks its
 //      candidates done).
@@ -23,7 +25,9 @@
 //   4. validation in two halves.  The new positions stay in LDS first and are probed against the pre-sweep positions of
 //      everything outside the cluster (the detection grid's lists).  A hit on a particle in no candidate pulls it in
 //      (compare-and-swap on slot_of) and the grown cluster is emulated again from the untouched pre-sweep state, up to
-//      CW_ITERS emulations; nothing of a superseded emulation was ever visible to another wave.  Then the FINAL
+//      CW_ITERS emulations; nothing of a superseded emulation was ever visible to another wave.  (A pair with one hit that
+//      pulls ONE particle in is not started over: the grown cluster's emulation reaches that hit with the same operands, so
+//      it continues from the hit's result under the same round tag, rs_first_hit.)  Then the FINAL
 //      emulation is published — write-through history records, each pushed on the overlay list of its grid cell by a
 //      compare-and-swap on the list head (a reader never meets a half-linked entry) — and only after ALL pushes of the
 //      wave have returned are the positions probed against the other clusters' new positions (the overlay lists, read
