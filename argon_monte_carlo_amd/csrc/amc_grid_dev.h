@@ -147,9 +147,14 @@ AMC_DEV void amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double 
     const bool mover = c != c_old;
     const unsigned long long mv = __ballot(mover);
     if (!mover) {
+#ifdef AMC_KEEP_FULLREC
+        r.next = B.rec[node].next;              // (experiment: whole 16-byte records written, as a full build does)
+        B.rec[node] = r;
+#else
         typedef float v3f_ __attribute__((ext_vector_type(3)));
         v3f_ v_; v_.x = r.x; v_.y = r.y; v_.z = r.z;
         *(v3f_ *)&B.rec[node] = v_;             // (one 12-byte store; the link behind it is untouched)
+#endif
     }
     if (mv == 0ULL) return;
     const int lane = (int)__lane_id();

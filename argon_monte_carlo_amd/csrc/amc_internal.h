@@ -67,9 +67,8 @@ struct amc_lists {
     int *bank_count;          // [AMC_KEEP_BANKS] nodes handed out since the last full build
     int bank_cap;             // nodes per bank
 };
-#define AMC_LIST_KEEP_DEFAULT_PORE 0      // (switched on once measured)
+#define AMC_LIST_KEEP_DEFAULT_PORE 4      // (specular pore: 126.4 against 130.8 us per step at N = 1e6, 75.5 against 77.6 at 5e5; K = 3 the same, 6 and 8 less)
 #define AMC_KEEP_BANKS 256
-#define AMC_KEEP_DET_J 8      // blocks of the detect kernel per bank of extra nodes
 #define AMC_EXTRA_NODES(n) ((int)std::min<long long>(std::max<long long>(4096, (long long)(n) / 64), 1 << 22))
 
 // What the streaming pass of an OVERLAPPED run needs beyond the plain one (amc_run): it reads the state the
