@@ -173,7 +173,7 @@ void amc_destroy(amc_ctx *c)
     void *ptrs[] = {c->s_slab, c->s_slab2, c->d_lay, c->B_buf[0].rec, c->B_buf[0].head, c->B_buf[1].rec, c->B_buf[1].head,
                     c->extra_buf[0], c->extra_count, c->wev_buf[0].rec, c->wev_buf[0].count, c->ovl_flags,
                     c->W.ov_head, c->w_slab, c->d_rec, c->d_hist, c->d_edges, c->d_cnt, c->d_banks, c->d_dbg,
-                    c->B_buf[0].cell_of, c->B_buf[0].node_of, c->B_buf[0].bank_count, c->keep_K >= 2 ? (void *)c->B_buf[0].extra : nullptr};
+                    c->B_buf[0].cell_of, c->B_buf[0].node_of, c->B_buf[0].wave_count, c->keep_K >= 2 ? (void *)c->B_buf[0].extra : nullptr};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -308,20 +308,21 @@ int amc_create(amc_ctx **out, const amc_params *p)
             // files particles itself), for the energised pore (its wall cases move particles after the pass) and when the
             // all-pairs detector is in front.
             c->keep_K = 0; c->lists_age = -1; c->keep_threads = 0;
-            size_t pool = 0;
+            size_t pool = 0, keep_waves = 0;
             {
                 int K = (p->geometry == AMC_GEOM_PORE) ? AMC_LIST_KEEP_DEFAULT_PORE : 0;
                 if (const char *e = getenv("AMC_LIST_KEEP")) K = atoi(e);
                 if (c->overlap_mode || c->detect_ap || p->geometry == AMC_GEOM_PORE_ENERGISED || p->geometry == AMC_GEOM_CELL) K = 0;
                 const int threads = getenv("AMC_STREAM_BS") ? atoi(getenv("AMC_STREAM_BS")) : 256;
-                const long long nblocks = ((long long)n + threads - 1) / threads;
-                const long long per_bank = (nblocks + AMC_KEEP_BANKS - 1) / AMC_KEEP_BANKS;
-                // (a bank holds everything its blocks could hand out in K - 1 steps; shorter cycles rather than more than 2^30 nodes)
-                while (K >= 2 && (long long)n + per_bank * threads * (K - 1) * AMC_KEEP_BANKS > 0x3fffffffLL) K--;
-                if (K >= 2 && n > 0) {
+                const long long nwaves = (((long long)n + threads - 1) / threads) * (threads / 64);
+                // (a wave's pool holds everything its 64 particles could hand out in K - 1 steps; shorter cycles rather than more
+                // than 2^30 nodes)
+                while (K >= 2 && (long long)n + nwaves * 64 * (K - 1) > 0x3fffffffLL) K--;
+                if (K >= 2 && n > 0 && threads % 64 == 0) {
                     c->keep_K = K; c->keep_threads = threads;
-                    c->B.bank_cap = (int)(per_bank * threads * (K - 1));
-                    pool = (size_t)c->B.bank_cap * AMC_KEEP_BANKS;
+                    c->B.wave_cap = 64 * (K - 1);
+                    pool = (size_t)c->B.wave_cap * (size_t)nwaves;
+                    keep_waves = (size_t)nwaves;
                 }
             }
             CK(dalloc(&c->B.rec, n + std::max((size_t)c->max_extra, pool)));
@@ -329,15 +330,15 @@ int amc_create(amc_ctx **out, const amc_params *p)
             CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));
             c->B.epoch = 0;
             c->B.n = (int)c->n; c->B.extra = nullptr;
-            c->B.cell_of = c->B.node_of = c->B.bank_count = nullptr;
+            c->B.cell_of = c->B.node_of = c->B.wave_count = nullptr;
             if (c->keep_K >= 2) {
                 CK(dalloc(&c->B.extra, pool));
                 CK(dalloc(&c->B.cell_of, n));
                 CK(dalloc(&c->B.node_of, n));
-                CK(dalloc(&c->B.bank_count, AMC_KEEP_BANKS));
-                CK(hipMemsetAsync(c->B.bank_count, 0, sizeof(int) * AMC_KEEP_BANKS, c->stream));
+                CK(dalloc(&c->B.wave_count, keep_waves));
+                CK(hipMemsetAsync(c->B.wave_count, 0, sizeof(int) * keep_waves, c->stream));
             } else {
-                c->B.bank_cap = 0;
+                c->B.wave_cap = 0;
             }
             c->B_buf[0] = c->B;
             CK(dalloc(&c->W.ov_head, nc));

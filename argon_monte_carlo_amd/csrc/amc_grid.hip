@@ -106,8 +106,17 @@ AMC_DEV int amc_push_candidate(int a, int b, int max_cand, amc_dev_counters *cnt
 AMC_DEV void amc_detect_node(const amc_grid &G, const amc_lists &B, int node, double cr2i, double cr_probe, int max_cand,
                              amc_dev_counters *cnt, const amc_adj &D)
 {
-    const amc_rec me_r = B.rec[node];
-    if (me_r.x != me_r.x) return;       // a particle's own node after the particle was filed again under an extra node (amc_lists)
+    amc_rec me_r = B.rec[node];
+    if (me_r.x != me_r.x) {
+        // a particle's own node after the particle was filed again under another one.  Kept lists: THIS thread walks for the
+        // live node (one node per thread whatever moved; blocks of their own for the extra nodes cost what blocks of
+        // particles cost, whether they find work or not — 2,048 of them were +21 us).  An overlapped run (no node_of): the
+        // extra nodes have blocks of their own.
+        if (!B.node_of || node >= B.n) return;
+        node = B.node_of[node];
+        me_r = B.rec[node];
+        if (me_r.x != me_r.x) return;
+    }
     const int me_p = amc_node_particle(B, node);
     double3 me;
     amc_rec_pos(G, me_r, me.x, me.y, me.z);
@@ -169,7 +178,6 @@ AMC_DEV void amc_detect_node(const amc_grid &G, const amc_lists &B, int node, do
                                 // 6 waves bought with spills (96 / 80 registers) 36.0 / 42.4 us against 35.9; the candidate push
                                 // as a real call instead of inlined (116 registers, but the call's frame) 48 us
 #endif
-template <bool KEPT>
 __global__ __launch_bounds__(256, AMC_DETECT_MINW) void k_detect_lists(amc_grid G, amc_lists B, long long n, double cr2i, double cr_probe,
                                                       int max_cand, amc_dev_counters *cnt, amc_adj D, const int *extra_count,
                                                       int max_extra)
@@ -178,20 +186,9 @@ __global__ __launch_bounds__(256, AMC_DETECT_MINW) void k_detect_lists(amc_grid 
     if ((long long)blockIdx.x < nb) {
         const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
         if (p < n) amc_detect_node(G, B, (int)p, cr2i, cr_probe, max_cand, cnt, D);
-        if (KEPT) {
-            // kept lists: the extra nodes are walked by the SAME blocks — bank b mod banks, the blocks of a bank share its
-            // entries.  Blocks of their own for them cost what a block of particles costs whether or not they find work
-            // (measured: 2.3 ns per wave of this kernel, busy or leaving at once; 2,048 such blocks were +21 us).
-            const int bank = (int)(blockIdx.x % AMC_KEEP_BANKS), q = (int)(blockIdx.x / AMC_KEEP_BANKS);
-            const int Q = (int)((nb + AMC_KEEP_BANKS - 1) / AMC_KEEP_BANKS);
-            int ne = B.bank_count[bank];
-            if (ne > B.bank_cap) ne = B.bank_cap;
-            for (int e = q * (int)blockDim.x + (int)threadIdx.x; e < ne; e += Q * (int)blockDim.x)
-                amc_detect_node(G, B, (int)n + bank * B.bank_cap + e, cr2i, cr_probe, max_cand, cnt, D);
-        }
         return;
     }
-    if (KEPT || !extra_count) return;
+    if (!extra_count) return;
     // (an overlapped run: a few more blocks for the particles its fix-up kernel filed again under extra nodes)
     int ne = *extra_count;
     if (ne > max_extra) ne = max_extra;
@@ -431,20 +428,15 @@ hipError_t amc_launch_detect(amc_ctx *c)
         }
     } else {
         // (an overlapped run: four more blocks for the particles the fix-up kernel filed again under extra nodes)
-        const bool kept = c->keep_K >= 2 && c->lists_age > 0;       // kept lists with extra nodes in use
-        const bool extras = !kept && c->B.extra != nullptr && c->keep_K < 2;
+        const bool extras = c->B.extra != nullptr && c->keep_K < 2;
         const int slot = (c->B.extra == c->extra_buf[1]) ? 1 : 0;
         static const int bs = getenv("AMC_DETECT_BS") ? atoi(getenv("AMC_DETECT_BS")) : 256;      // (experiments: 64 / 128 / 256)
         // (occupancy is not what bounds this kernel: capped at 4 waves per SIMD instead of 5 it takes the same 36.7 us at
         // N = 1e6, at 2 it takes 59 — it runs at the rate of its random requests; two or four particles per thread,
         // one after the other, change nothing at N = 1e6 and cost 5 / 15 us at N = 1e5)
-        const dim3 grid((unsigned)((n + bs - 1) / bs) + (extras ? 4u : 0u));
-        if (kept)
-            AMC_LAUNCH(c, k_detect_lists<true>, grid, dim3(bs), c->G, c->B, n, cr2i, c->G.cr_probe, c->W.max_cand, c->d_cnt, D,
-                       (const int *)nullptr, 0);
-        else
-            AMC_LAUNCH(c, k_detect_lists<false>, grid, dim3(bs), c->G, c->B, n, cr2i, c->G.cr_probe, c->W.max_cand, c->d_cnt, D,
-                       (const int *)(extras ? c->extra_count + slot : nullptr), c->max_extra);
+        AMC_LAUNCH(c, k_detect_lists, dim3((unsigned)((n + bs - 1) / bs) + (extras ? 4u : 0u)), dim3(bs), c->G, c->B, n, cr2i,
+                   c->G.cr_probe, c->W.max_cand, c->d_cnt, D, (const int *)(extras ? c->extra_count + slot : nullptr),
+                   c->max_extra);
     }
     amc_prof_end(c);
     return hipGetLastError();

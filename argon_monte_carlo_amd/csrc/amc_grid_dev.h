@@ -123,10 +123,11 @@ AMC_DEV void amc_list_insert(const amc_grid &G, const amc_lists &B, int p, doubl
 
 // Kept lists (amc_lists): file particle p at (x, y, z).  full: every particle under its own node, as amc_list_insert, and
 // cell / node remembered.  Otherwise: same cell as last step -> only the node's position is refreshed; another cell -> the
-// old node is poisoned (stays linked) and a new node is taken from the block's bank and pushed on the new cell's list.
-// Must be called by all active lanes of a wave together (the node allocation is one increment per wave).
-AMC_DEV void amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double x, double y, double z, bool full, int bank,
-                           bool *outside, bool *overflow)
+// old node is poisoned (stays linked) and a new node is taken from the WAVE's pool (count0 = what the wave had handed out
+// before this step, read by the caller together with the state) and pushed on the new cell's list.  Must be called by all
+// active lanes of a wave together; returns the wave's new count (the caller's first active lane stores it).
+AMC_DEV int amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double x, double y, double z, bool full, int wave_id,
+                          int count0, bool *outside, bool *overflow)
 {
     amc_rec r;
     r.x = (float)(x - G.x0); r.y = (float)(y - G.y0); r.z = (float)(z - G.z0);
@@ -141,35 +142,26 @@ AMC_DEV void amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double 
         r.next = ((unsigned int)(old >> 32) == B.epoch) ? (int)(unsigned int)(old & 0xffffffffULL) : -1;
         B.rec[p] = r;
         B.cell_of[p] = c; B.node_of[p] = p;
-        return;
+        return 0;
     }
     const int c_old = B.cell_of[p], node = B.node_of[p];
     const bool mover = c != c_old;
     const unsigned long long mv = __ballot(mover);
     if (!mover) {
-#ifdef AMC_KEEP_FULLREC
-        r.next = B.rec[node].next;              // (experiment: whole 16-byte records written, as a full build does)
-        B.rec[node] = r;
-#else
         typedef float v3f_ __attribute__((ext_vector_type(3)));
         v3f_ v_; v_.x = r.x; v_.y = r.y; v_.z = r.z;
         *(v3f_ *)&B.rec[node] = v_;             // (one 12-byte store; the link behind it is untouched)
-#endif
+        return count0 + __popcll(mv);
     }
-    if (mv == 0ULL) return;
     const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)mv) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&B.bank_count[bank], __popcll(mv));
-    base = __shfl(base, leader);
-    if (!mover) return;
-    const int idx = base + __popcll(mv & ((1ULL << lane) - 1ULL));
+    const int idx = count0 + __popcll(mv & ((1ULL << lane) - 1ULL));
     ((float *)&B.rec[node])[0] = __int_as_float(0x7fc00000);        // the node it leaves: NaN, no test passes; its link stays
-    if (idx >= B.bank_cap) { *overflow = true; return; }            // (cannot happen: a bank holds what its blocks can hand out)
-    const int e = bank * B.bank_cap + idx, nn = B.n + e;
+    if (idx >= B.wave_cap) { *overflow = true; return count0 + __popcll(mv); }     // (cannot happen: see amc_lists)
+    const int e = wave_id * B.wave_cap + idx, nn = B.n + e;
     B.extra[e] = p; B.node_of[p] = nn; B.cell_of[p] = c;
     const unsigned long long mine = ((unsigned long long)B.epoch << 32) | (unsigned int)nn;
     const unsigned long long old = atomicExch(&B.head[c], mine);
     r.next = ((unsigned int)(old >> 32) == B.epoch) ? (int)(unsigned int)(old & 0xffffffffULL) : -1;
     B.rec[nn] = r;
+    return count0 + __popcll(mv);
 }

@@ -59,16 +59,15 @@ struct amc_lists {
     // KEPT lists (amc_list_keep, amc_grid_dev.h): the lists of a full build live on for keep_K - 1 more steps.  A
     // particle that is still in the cell it is filed under only refreshes the position in its node; one that left gives its
     // node a position no test passes (the node stays linked: walkers pass through it) and files a NEW node n + e in its new
-    // cell — one atomic exchange for the ~6 % that change cell per step in the pore instead of one per particle.  Nodes come
-    // from AMC_KEEP_BANKS pools (bank = block of the streaming pass mod banks, one counter each, one increment per wave);
-    // a pool holds what its blocks can hand out in keep_K - 1 steps, so it cannot run out.
+    // cell — one atomic exchange for the ~6 % that change cell per step in the pore instead of one per particle.  Every WAVE
+    // of the streaming pass has a pool of its own (64 x (keep_K - 1) nodes: each of its particles can move once per step, so
+    // it cannot run out) and a counter only it touches — no atomic, no wait: read with the state, written at the end.
     int *cell_of;             // [n] cell the particle's live node is filed under
     int *node_of;             // [n] that node
-    int *bank_count;          // [AMC_KEEP_BANKS] nodes handed out since the last full build
-    int bank_cap;             // nodes per bank
+    int *wave_count;          // [waves of the streaming pass] nodes the wave has handed out since the last full build
+    int wave_cap;             // nodes per wave
 };
 #define AMC_LIST_KEEP_DEFAULT_PORE 4      // (specular pore: 126.4 against 130.8 us per step at N = 1e6, 75.5 against 77.6 at 5e5; K = 3 the same, 6 and 8 less)
-#define AMC_KEEP_BANKS 256
 #define AMC_EXTRA_NODES(n) ((int)std::min<long long>(std::max<long long>(4096, (long long)(n) / 64), 1 << 22))
 
 // What the streaming pass of an OVERLAPPED run needs beyond the plain one (amc_run): it reads the state the

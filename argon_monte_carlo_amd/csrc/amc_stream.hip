@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_state S_out, am
     // an overlapped run: the sweep of the previous step is still being resolved.  Particles its detect kernel
     // linked into a candidate are left to the fix-up kernel, which advances them from the sweep's results.
     if (V.skip_epoch && (unsigned int)(V.adj_head[p] >> 32) == V.skip_epoch) return;      // (epoch 0: no sweep in flight)
+    // (kept lists, a step in between: what this wave has handed out of its node pool so far — one word only it touches)
+    const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int keep_count0 = build_lists == 3 ? B.wave_count[wave_id] : 0;
     amc_particle q;
     q.x = AMC_LD(S.x[p]); q.y = AMC_LD(S.y[p]); q.z = AMC_LD(S.z[p]);
     q.vx = AMC_LD(S.vx[p]); q.vy = AMC_LD(S.vy[p]); q.vz = AMC_LD(S.vz[p]);
@@ -189,8 +192,8 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_state S_out, am
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
     } else if (build_lists) {
         bool outside = false, overflow = false;
-        if (build_lists == 2 && threadIdx.x == 0 && blockIdx.x < AMC_KEEP_BANKS) B.bank_count[blockIdx.x] = 0;
-        amc_list_keep(G, B, (int)p, q.x, q.y, q.z, build_lists == 2, (int)(blockIdx.x & (AMC_KEEP_BANKS - 1)), &outside, &overflow);
+        const int nc = amc_list_keep(G, B, (int)p, q.x, q.y, q.z, build_lists == 2, wave_id, keep_count0, &outside, &overflow);
+        if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) B.wave_count[wave_id] = nc;     // (the wave's own word)
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
         if (overflow) atomicOr(&O.cnt->flags, 1ULL);
     }

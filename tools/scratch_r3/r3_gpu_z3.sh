@@ -11,5 +11,5 @@ d=json.load(open('gpurun_out/keep/x_$2_K$1_$3.json')); r=d['roofline']['per_kern
 print('$2 K=$1','%.1f (s %.1f d %.1f c %.1f)'%(d['ms_per_step']*1e3, r.get('drift_walls',0), r.get('detect',0), r.get('clusters_wide',0)))
 PY
 }
-for rep in 1 2; do for K in 0 3 4 6 8; do run $K pore_1e6 $rep; done; done
-for K in 0 4; do run $K pore_5e5 1; run $K cube_1e5 1; done
+for rep in 1 2; do for K in 0 3 4 6 8 12; do run $K pore_1e6 $rep; done; done
+for K in 0 4 8; do run $K pore_5e5 1; done; for K in 0 2 3; do run $K cube_1e6 1; done; run 0 cube_1e5 1; run 2 cube_1e5 1
