@@ -124,10 +124,10 @@ AMC_DEV void amc_list_insert(const amc_grid &G, const amc_lists &B, int p, doubl
 // Kept lists (amc_lists): file particle p at (x, y, z).  full: every particle under its own node, as amc_list_insert, and
 // cell / node remembered.  Otherwise: same cell as last step -> only the node's position is refreshed; another cell -> the
 // old node is poisoned (stays linked) and a new node is taken from the WAVE's pool (count0 = what the wave had handed out
-// before this step, read by the caller together with the state) and pushed on the new cell's list.  Must be called by all
+// before this step; like c_old / node — the particle's cell_of / node_of — read by the caller together with the state) and pushed on the new cell's list.  Must be called by all
 // active lanes of a wave together; returns the wave's new count (the caller's first active lane stores it).
 AMC_DEV int amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double x, double y, double z, bool full, int wave_id,
-                          int count0, bool *outside, bool *overflow)
+                          int count0, int c_old, int node, bool *outside, bool *overflow)
 {
     amc_rec r;
     r.x = (float)(x - G.x0); r.y = (float)(y - G.y0); r.z = (float)(z - G.z0);
@@ -144,8 +144,7 @@ AMC_DEV int amc_list_keep(const amc_grid &G, const amc_lists &B, int p, double x
         B.cell_of[p] = c; B.node_of[p] = p;
         return 0;
     }
-    const int c_old = B.cell_of[p], node = B.node_of[p];
-    const bool mover = c != c_old;
+    const bool mover = c != c_old;      // (c_old, node: where the particle is filed — read by the caller together with the state)
     const unsigned long long mv = __ballot(mover);
     if (!mover) {
         typedef float v3f_ __attribute__((ext_vector_type(3)));

@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_state S_out, am
     // (kept lists, a step in between: what this wave has handed out of its node pool so far — one word only it touches)
     const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int keep_count0 = build_lists == 3 ? B.wave_count[wave_id] : 0;
+    // (and where the particle is filed: asked for now, needed at the very end — there the round trip would be the wave's last)
+    const int keep_cell = build_lists == 3 ? B.cell_of[p] : -1, keep_node = build_lists == 3 ? B.node_of[p] : (int)p;
     amc_particle q;
     q.x = AMC_LD(S.x[p]); q.y = AMC_LD(S.y[p]); q.z = AMC_LD(S.z[p]);
     q.vx = AMC_LD(S.vx[p]); q.vy = AMC_LD(S.vy[p]); q.vz = AMC_LD(S.vz[p]);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void k_stream(amc_state S, amc_state S_out, am
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
     } else if (build_lists) {
         bool outside = false, overflow = false;
-        const int nc = amc_list_keep(G, B, (int)p, q.x, q.y, q.z, build_lists == 2, wave_id, keep_count0, &outside, &overflow);
+        const int nc = amc_list_keep(G, B, (int)p, q.x, q.y, q.z, build_lists == 2, wave_id, keep_count0, keep_cell, keep_node, &outside, &overflow);
         if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) B.wave_count[wave_id] = nc;     // (the wave's own word)
         if (outside) atomicOr(&O.cnt->flags, 8ULL);
         if (overflow) atomicOr(&O.cnt->flags, 1ULL);
