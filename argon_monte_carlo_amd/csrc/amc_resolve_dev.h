@@ -385,9 +385,11 @@ AMC_DEV bool rs_emulate_pair_io(const rs_args &A, rs_shared *sh, amc_particle &p
             if (hit_g < 0) break;
             if (rs_hit(A, sh, p1, p2, pj, pi, sj, si, 16 + hit_g, hit_c, wd)) {
                 moved = true;
-                rs_pore_ks(A, p1, k1);
-                rs_pore_ks(A, p2, k2);
                 ov = amc_overlap(p1.x, p1.y, p1.z, p2.x, p2.y, p2.z, cr);
+                if (ov) {                   // (the cells are only needed if the pair can hit again: it almost never can)
+                    rs_pore_ks(A, p1, k1);
+                    rs_pore_ks(A, p2, k2);
+                }
             }
             g = hit_g + 1;
         }
@@ -550,8 +552,10 @@ AMC_DEV void rs_emulate_small(const rs_args &A, rs_shared *sh, amc_particle (&q)
                 for (int c = 0; c < a; c++)
                     if (ovp[c][a] && cell[a] >= 0 && cell[c] == cell[a]) {
                         hit(c, a, q[c], q[a], pidx[c], pidx[a], slot[c], slot[a], 16 + g, cell[a]);
-                        rs_pore_ks(A, q[c], ks[c]);
-                        rs_pore_ks(A, q[a], ks[a]);
+                        if (any) {          // (cells are looked at again only while some pair overlaps)
+                            rs_pore_ks(A, q[c], ks[c]);
+                            rs_pore_ks(A, q[a], ks[a]);
+                        }
                     }
         }
     }
