@@ -107,13 +107,16 @@ AMC_DEV void amc_detect_node(const amc_grid &G, const amc_lists &B, int node, do
                              amc_dev_counters *cnt, const amc_adj &D)
 {
     amc_rec me_r = B.rec[node];
+    // (kept lists: where the particle's live node is — asked for together with the record, so that a moved particle costs its
+    // wave one more round trip, not two; at 6 % movers nearly every wave has one)
+    const int live = (B.node_of && node < B.n) ? B.node_of[node] : node;
     if (me_r.x != me_r.x) {
         // a particle's own node after the particle was filed again under another one.  Kept lists: THIS thread walks for the
         // live node (one node per thread whatever moved; blocks of their own for the extra nodes cost what blocks of
         // particles cost, whether they find work or not — 2,048 of them were +21 us).  An overlapped run (no node_of): the
         // extra nodes have blocks of their own.
-        if (!B.node_of || node >= B.n) return;
-        node = B.node_of[node];
+        if (live == node) return;
+        node = live;
         me_r = B.rec[node];
         if (me_r.x != me_r.x) return;
     }
