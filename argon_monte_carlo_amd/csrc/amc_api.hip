@@ -173,7 +173,7 @@ void amc_destroy(amc_ctx *c)
     void *ptrs[] = {c->s_slab, c->s_slab2, c->d_lay, c->B_buf[0].rec, c->B_buf[0].head, c->B_buf[1].rec, c->B_buf[1].head,
                     c->extra_buf[0], c->extra_count, c->wev_buf[0].rec, c->wev_buf[0].count, c->ovl_flags,
                     c->W.ov_head, c->w_slab, c->d_rec, c->d_hist, c->d_edges, c->d_cnt, c->d_banks, c->d_dbg,
-                    c->B_buf[0].cell_of, c->B_buf[0].node_of, c->B_buf[0].wave_count, c->keep_K >= 2 ? (void *)c->B_buf[0].extra : nullptr};
+                    c->B_buf[0].cell_of, c->B_buf[0].node_of, c->B_buf[0].wave_count, c->mg_wave_count, c->keep_K >= 2 ? (void *)c->B_buf[0].extra : nullptr};
     for (void *p : ptrs)
         if (p) hipFree(p);
     if (c->h_host_ncand) hipHostFree((void *)c->h_host_ncand);
@@ -229,6 +229,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
     memset(c->k_launches, 0, sizeof c->k_launches);
     memset(&c->S, 0, sizeof c->S); memset(&c->B, 0, sizeof c->B); memset(&c->W, 0, sizeof c->W);
     memset(c->S_buf, 0, sizeof c->S_buf); memset(c->B_buf, 0, sizeof c->B_buf); memset(c->wev_buf, 0, sizeof c->wev_buf);
+    c->mg_wave_count = nullptr; c->mg_waves_pack = c->mg_waves_unpack = 0; c->mg_keep = false; c->kin_mode = 1; c->keep_pool = 0;
     c->s_slab2 = nullptr; c->extra_buf[0] = c->extra_buf[1] = nullptr; c->extra_count = nullptr; c->max_extra = 0;
     c->stream2 = nullptr; c->ev_detect = c->ev_stream = nullptr;
     c->ovl_flags = nullptr; c->ovl_tick = 0;
@@ -307,7 +308,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
             // kept lists (amc_lists): AMC_LIST_KEEP=K, a full build every K steps.  Off in an overlapped run (its fix-up kernel
             // files particles itself), for the energised pore (its wall cases move particles after the pass) and when the
             // all-pairs detector is in front.
-            c->keep_K = 0; c->lists_age = -1; c->keep_threads = 0;
+            c->keep_K = 0; c->lists_age = -1; c->lists_owner = 0; c->keep_threads = 0;
             size_t pool = 0, keep_waves = 0;
             {
                 int K = (p->geometry == AMC_GEOM_PORE) ? AMC_LIST_KEEP_DEFAULT_PORE : 0;
@@ -325,6 +326,7 @@ int amc_create(amc_ctx **out, const amc_params *p)
                     keep_waves = (size_t)nwaves;
                 }
             }
+            c->keep_pool = pool;
             CK(dalloc(&c->B.rec, n + std::max((size_t)c->max_extra, pool)));
             CK(dalloc(&c->B.head, nc + 1));
             CK(hipMemsetAsync(c->B.head, 0, sizeof(unsigned long long) * (nc + 1), c->stream));

@@ -46,6 +46,31 @@ int amc_mg_exchange_view(amc_ctx *c, int world, void **send, void **recv, int64_
         AMC_HIP(c, hipMalloc((void **)&c->kin_recv, sizeof(double) * (size_t)c->kin_block * (size_t)world));
         c->kin_world = world;
         c->kin_counts_clear = false;
+        // kept lists (pore): a node pool per wave of the pack and of the unpack kernel, whose launch geometry is fixed by the
+        // world size; the node records behind the particles' own grow if these pools need more than the single-GPU pass's
+        c->mg_keep = false;
+        c->lists_age = -1;
+        if (c->mg_wave_count) { hipFree(c->mg_wave_count); c->mg_wave_count = nullptr; }
+        if (c->keep_K >= 2 && c->B.cell_of && c->B_buf[0].rec == c->B.rec) {
+            const int64_t per = std::max<int64_t>(c->kin_m, c->kin_cap);
+            c->mg_waves_pack = (int)((c->kin_m + 255) / 256) * 4;
+            c->mg_waves_unpack = (int)(((int64_t)world * per + 255) / 256) * 4;
+            const size_t waves = (size_t)c->mg_waves_pack + (size_t)c->mg_waves_unpack;
+            const size_t pool = waves * (size_t)c->B.wave_cap;
+            if ((long long)c->n + (long long)pool <= 0x3fffffffLL) {
+                if (pool > c->keep_pool) {
+                    amc_rec *rec = nullptr; int *extra = nullptr;
+                    AMC_HIP(c, dalloc(&rec, (size_t)c->n + std::max((size_t)c->max_extra, pool)));
+                    AMC_HIP(c, dalloc(&extra, pool));
+                    hipFree(c->B.rec); hipFree(c->B.extra);
+                    c->B.rec = rec; c->B.extra = extra; c->keep_pool = pool;
+                    c->B_buf[0].rec = rec; c->B_buf[0].extra = extra;
+                }
+                AMC_HIP(c, dalloc(&c->mg_wave_count, waves));
+                AMC_HIP(c, hipMemsetAsync(c->mg_wave_count, 0, sizeof(int) * waves, c->stream));
+                c->mg_keep = true;
+            }
+        }
     }
     *send = c->kin_send; *recv = c->kin_recv; *block = c->kin_block;
     return AMC_OK;

@@ -22,10 +22,15 @@ struct kin_arrays {
 
 __global__ __launch_bounds__(256) void k_kin_pack(kin_arrays S, long long lo, long long hi, long long m, long long capb,
                                                   double *__restrict__ send, amc_grid G, amc_lists B,
-                                                  amc_dev_counters *cnt)
+                                                  amc_dev_counters *cnt, int mode)
 {
     const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = u < m && lo + u < hi;
+    // (kept lists, amc_lists: mode 2 the full build of a cycle, 3 a step in between — the wave's pool count and where the
+    // particle is filed are asked for now, with the state)
+    const int wave_id = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    int keep_count0 = 0, keep_cell = -1, keep_node = -1;
+    if (in && mode == 3) { keep_count0 = B.wave_count[wave_id]; keep_cell = B.cell_of[lo + u]; keep_node = B.node_of[lo + u]; }
     double pos[3] = {0.0, 0.0, 0.0};
     bool changed = false;
     double v[3];
@@ -43,9 +48,16 @@ __global__ __launch_bounds__(256) void k_kin_pack(kin_arrays S, long long lo, lo
         for (int e = 0; e < 3; e++) send[e * m + u] = pos[e];
     }
     if (in) {
-        bool outside = false;
-        amc_list_insert(G, B, (int)(lo + u), pos[0], pos[1], pos[2], &outside);
+        bool outside = false, overflow = false;
+        if (mode == 1) {
+            amc_list_insert(G, B, (int)(lo + u), pos[0], pos[1], pos[2], &outside);
+        } else {
+            const int nc = amc_list_keep(G, B, (int)(lo + u), pos[0], pos[1], pos[2], mode == 2, wave_id, keep_count0, keep_cell, keep_node,
+                                         &outside, &overflow);
+            if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) B.wave_count[wave_id] = nc;
+        }
         if (outside) atomicOr(&cnt->flags, 8ULL);
+        if (overflow) atomicOr(&cnt->flags, 1ULL);
     }
     // slots of the changed particles: one increment of the bank's counter per workgroup
     __shared__ int s_n;
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256) void k_kin_pack(kin_arrays S, long long lo, lo
 __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, int world, int rank, long long m, long long capb,
                                                     const double *__restrict__ recv, amc_grid G, amc_lists B,
                                                     amc_dev_counters *cnt, int *__restrict__ slot_of,
-                                                    double *__restrict__ send)
+                                                    double *__restrict__ send, int mode, int wave_base)
 {
     const long long cap = capb * AMC_KIN_BANKS, per = m > cap ? m : cap;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -88,6 +100,9 @@ __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, i
     const long long base = n / world, rem = n % world;
     const long long lo = r * base + (r < rem ? r : rem), len = base + (r < rem ? 1 : 0);
     if (u < len) {
+        const int wave_id = wave_base + (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        int keep_count0 = 0, keep_cell = -1, keep_node = -1;
+        if (mode == 3) { keep_count0 = B.wave_count[wave_id]; keep_cell = B.cell_of[lo + u]; keep_node = B.node_of[lo + u]; }
         double pos[3];
 #pragma unroll
         for (int e = 0; e < 3; e++) {
@@ -98,9 +113,16 @@ __global__ __launch_bounds__(256) void k_kin_unpack(kin_arrays S, long long n, i
         // arrive from the owners (positions above, velocities in the lists below) — only the slot is released (own
         // particles: the streaming pass took theirs)
         if (slot_of[lo + u] >= 0) slot_of[lo + u] = -1;
-        bool outside = false;
-        amc_list_insert(G, B, (int)(lo + u), pos[0], pos[1], pos[2], &outside);
+        bool outside = false, overflow = false;
+        if (mode == 1) {
+            amc_list_insert(G, B, (int)(lo + u), pos[0], pos[1], pos[2], &outside);
+        } else {
+            const int nc = amc_list_keep(G, B, (int)(lo + u), pos[0], pos[1], pos[2], mode == 2, wave_id, keep_count0, keep_cell, keep_node,
+                                         &outside, &overflow);
+            if ((int)__lane_id() == __ffsll((long long)__ballot(true)) - 1) B.wave_count[wave_id] = nc;
+        }
         if (outside) atomicOr(&cnt->flags, 8ULL);
+        if (overflow) atomicOr(&cnt->flags, 1ULL);
     }
     if (u < cap) {
         const long long bank = u / capb, k = u % capb;
@@ -122,9 +144,20 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
     S.a[0] = c->S.x; S.a[1] = c->S.y; S.a[2] = c->S.z; S.a[3] = c->S.vx; S.a[4] = c->S.vy; S.a[5] = c->S.vz;
     S.pub[0] = c->kin_vpub; S.pub[1] = c->kin_vpub + c->n; S.pub[2] = c->kin_vpub + 2 * c->n;
     amc_prof_begin(c, AMC_K_BIN_COUNT);       // (the list build is what these kernels cost)
+    amc_lists Bm = c->B;
+    Bm.wave_count = c->mg_wave_count;       // (kept lists: the exchange kernels' own pools)
     if (!unpack) {
-        c->lists_age = -1;
-        c->B.epoch++;                           // a new set of lists: this shard now, the other shards at the unpack
+        // a new set of lists — this shard now, the other shards at the unpack — or, with kept lists (pore), a step of a cycle
+        if (c->mg_keep) {
+            if (c->lists_owner != 2) c->lists_age = -1;
+            c->lists_owner = 2;
+            if (c->lists_age < 0 || c->lists_age + 1 >= c->keep_K) { c->kin_mode = 2; c->B.epoch++; c->lists_age = 0; }
+            else { c->kin_mode = 3; c->lists_age++; }
+        } else {
+            c->kin_mode = 1; c->lists_age = -1; c->B.epoch++;
+        }
+        Bm = c->B;
+        Bm.wave_count = c->mg_wave_count;
         c->kin_lists = true;
         if (!c->kin_counts_clear) {             // (normally the previous step's unpack kernel has cleared the banks' counters)
             hipError_t e = hipMemsetAsync(c->kin_send + 3 * m, 0, sizeof(double) * AMC_KIN_BANKS, c->stream);
@@ -132,11 +165,12 @@ hipError_t amc_launch_kin_pack(amc_ctx *c, int world, int rank, int unpack)
         }
         c->kin_counts_clear = false;
         AMC_LAUNCH(c, k_kin_pack, dim3((unsigned)((m + 255) / 256)), dim3(256), S, (long long)c->lo,
-                           (long long)c->hi, m, capb, c->kin_send, c->G, c->B, c->d_cnt);
+                           (long long)c->hi, m, capb, c->kin_send, c->G, Bm, c->d_cnt, c->kin_mode);
     } else {
         const long long per = m > c->kin_cap ? m : c->kin_cap;
         AMC_LAUNCH(c, k_kin_unpack, dim3((unsigned)(((long long)world * per + 255) / 256)), dim3(256), S,
-                           (long long)c->n, world, rank, m, capb, c->kin_recv, c->G, c->B, c->d_cnt, c->W.slot_of, c->kin_send);
+                           (long long)c->n, world, rank, m, capb, c->kin_recv, c->G, Bm, c->d_cnt, c->W.slot_of, c->kin_send, c->kin_mode,
+                           c->mg_waves_pack);
         c->kin_counts_clear = true;
     }
     amc_prof_end(c);

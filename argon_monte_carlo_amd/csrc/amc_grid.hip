@@ -211,7 +211,14 @@ __global__ __launch_bounds__(256) void k_detect_own(amc_grid G, amc_lists B, lon
 {
     const long long p = lo + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= hi) return;
-    const amc_rec me_r = B.rec[p];
+    amc_rec me_r = B.rec[p];
+    // (kept lists: a particle that has moved is walked for through its live node, asked for together with its own record)
+    const int live = B.node_of ? B.node_of[p] : (int)p;
+    if (me_r.x != me_r.x) {
+        if (live == (int)p) return;
+        me_r = B.rec[live];
+        if (me_r.x != me_r.x) return;
+    }
     double3 me;
     amc_rec_pos(G, me_r, me.x, me.y, me.z);
     int c_lo[4], c_hi[4];
@@ -245,9 +252,11 @@ __global__ __launch_bounds__(256) void k_detect_own(amc_grid G, amc_lists B, lon
                 double ox, oy, oz;
                 amc_rec_pos(G, o[e], ox, oy, oz);
                 const double ex = ox - me.x, ey = oy - me.y, ez = oz - me.z;
-                if (q[e] < (int)p && ex * ex + ey * ey + ez * ez < cr2i) {
+                // (a list entry is a NODE: the partner is the particle it stands for; my own live node is no partner)
+                const int pq = amc_node_particle(B, q[e]);
+                if (pq < (int)p && ex * ex + ey * ey + ez * ez < cr2i) {
                     const int k = atomicAdd(&out[0], 1);
-                    if (k < cap) { out[2 + 2 * k] = (int)p; out[3 + 2 * k] = q[e]; }
+                    if (k < cap) { out[2 + 2 * k] = (int)p; out[3 + 2 * k] = pq; }
                     else atomicOr(&cnt->flags, 1ULL);       // (candidate overflow: the step reports AMC_ERR_CAPACITY)
                 }
                 q[e] = amc_rec_next(o[e]);

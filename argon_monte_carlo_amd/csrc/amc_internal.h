@@ -207,7 +207,8 @@ struct amc_ctx {
     int ovl_sync_values;      // ~2 us per dependency instead of ~8, tools/ubench_xstream.hip, but the resolve suffers more: DESIGN 4.2)
     int64_t ovl_steps;        // steps run overlapped so far
     int keep_K;               // kept lists: a full build every keep_K steps (< 2: every step, the lists are not kept)
-    int lists_age;            // steps since the last full build by the streaming pass (-1: the lists are not its own)
+    int lists_age;            // steps since the last full build of a kept cycle (-1: the lists are not a kept cycle's)
+    int lists_owner;          // who runs the cycle: 1 the streaming pass, 2 the multi-GPU exchange kernels (their node pools differ)
     int keep_threads;         // block size of the streaming pass the pools were sized for
     int overlap_mode;         // AMC_OVERLAP: 1 (default) two streams, 2 the same kernels in order on one stream (debug), 0 off
     amc_resolve_ws W;
@@ -256,6 +257,12 @@ struct amc_ctx {
     int64_t kin_m, kin_cap, kin_block;   // shard length (padded), capacity of the velocity-change list (all banks), 3m + banks + 4cap
     int *cand_send, *cand_recv;    // multi-GPU, detection sharded by index: this rank's candidate block ([0] count, [2 + 2k] pairs)
     int cand_cap, cand_world;      // and the blocks of all ranks (the second all-gather of a step); pairs per block
+    // kept lists in the exchange kernels (pore, amc_lists): pools per wave of the pack and of the unpack kernel
+    int *mg_wave_count;            // [mg_waves_pack + mg_waves_unpack]
+    int mg_waves_pack, mg_waves_unpack;
+    bool mg_keep;                  // the pools exist for the current world size
+    int kin_mode;                  // this step's list build: 1 anew, 2 full build of a kept cycle, 3 a step in between
+    size_t keep_pool;              // nodes behind the particles' own in B.rec / entries of B.extra
     bool kin_lists;                // amc_mg_pack started this step's per-cell lists (the unpack completes them)
     bool kin_counts_clear;         // the bank counters in kin_send are zero (cleared by the last unpack kernel)
 };

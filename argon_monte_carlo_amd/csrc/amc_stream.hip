@@ -331,6 +331,8 @@ hipError_t amc_launch_stream(amc_ctx *c, double dt, int stages, int bounds_slot,
     if (fuse_bin && !c->allpairs && c->lo == 0 && c->hi == c->n) {
         if (c->keep_K >= 2 && threads == c->keep_threads && c->B.cell_of) {
             // kept lists: a full build when the lists are not this pass's own or the cycle is over, else a step in between
+            if (c->lists_owner != 1) c->lists_age = -1;
+            c->lists_owner = 1;
             if (c->lists_age < 0 || c->lists_age + 1 >= c->keep_K) { build = 2; c->B.epoch++; c->lists_age = 0; }
             else { build = 3; c->lists_age++; }
         } else {
