@@ -306,14 +306,14 @@ int amc_create(amc_ctx **out, const amc_params *p)
             const size_t nc = (size_t)c->G.ncells;
             c->max_extra = AMC_EXTRA_NODES(c->n);
             // kept lists (amc_lists): AMC_LIST_KEEP=K, a full build every K steps.  Off in an overlapped run (its fix-up kernel
-            // files particles itself), for the energised pore (its wall cases move particles after the pass) and when the
-            // all-pairs detector is in front.
+            // files particles itself) and when the all-pairs detector is in front.  (The energised pore files its particles in
+            // the bounds pass that follows the wall cases, amc_temp_end: the same pass, the same cycle.)
             c->keep_K = 0; c->lists_age = -1; c->lists_owner = 0; c->keep_threads = 0;
             size_t pool = 0, keep_waves = 0;
             {
-                int K = (p->geometry == AMC_GEOM_PORE) ? AMC_LIST_KEEP_DEFAULT_PORE : 0;
+                int K = (p->geometry == AMC_GEOM_PORE || p->geometry == AMC_GEOM_PORE_ENERGISED) ? AMC_LIST_KEEP_DEFAULT_PORE : 0;
                 if (const char *e = getenv("AMC_LIST_KEEP")) K = atoi(e);
-                if (c->overlap_mode || c->detect_ap || p->geometry == AMC_GEOM_PORE_ENERGISED || p->geometry == AMC_GEOM_CELL) K = 0;
+                if (c->overlap_mode || c->detect_ap || p->geometry == AMC_GEOM_CELL) K = 0;
                 const int threads = getenv("AMC_STREAM_BS") ? atoi(getenv("AMC_STREAM_BS")) : 256;
                 const long long nwaves = (((long long)n + threads - 1) / threads) * (threads / 64);
                 // (a wave's pool holds everything its 64 particles could hand out in K - 1 steps; shorter cycles rather than more
