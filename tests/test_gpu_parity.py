@@ -1161,9 +1161,9 @@ def test_overlapped_run_equals_the_plain_sequence_at_size(Engine, O, monkeypatch
 @pytest.mark.parametrize("kind,n,sigma_mult,keep,steps", [("pore", 60_000, 30.0, 3, 14), ("pore", 200_000, 1.0, 8, 20),
                                                          ("cube", 30_000, 16.0, 4, 13)])
 def test_kept_lists_equal_the_oracle(Engine, O, monkeypatch, kind, n, sigma_mult, keep, steps):
-    """AMC_LIST_KEEP=K (opt-in): the per-cell lists of a full build are kept for K - 1 more steps — a particle
+    """AMC_LIST_KEEP=K (the pore's default is K = 4, here other K and the cube): the per-cell lists of a full build are kept for K - 1 more steps — a particle
     still in its cell refreshes the position in its node, one that left poisons its node and files a new one from its
-    block's pool.  Several cycles, run() and timestep() mixed (both go through the same lists), high collision rates so
+    wave's pool.  Several cycles, run() and timestep() mixed (both go through the same lists), high collision rates so
     that clusters, pulled-in particles and validation walk lists full of dead nodes: state, counters and completed paths
     equal the oracle's bit for bit at every step."""
     monkeypatch.setenv("AMC_LIST_KEEP", str(keep))
